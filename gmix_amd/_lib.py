@@ -1,0 +1,105 @@
+"""ctypes binding of libgmxmix.so (include/gmxmix.h).  The library is the product: if it is
+missing or cannot be loaded this module raises -- there is no Python or CPU fallback."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgmxmix.so")
+_LIB = None
+
+
+class GmxError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        L = _LIB
+        msg = L.gmx_strerror(status).decode() if L else str(status)
+        extra = L.gmx_last_error().decode() if (L and status == -3) else ""
+        super().__init__(f"{where}: {msg} [{status}] {extra}".strip())
+
+
+class MixerDesc(C.Structure):
+    _fields_ = [("layer", C.c_int32), ("table_size", C.c_uint32), ("learning_rate", C.c_float)]
+
+
+class TopologyStruct(C.Structure):
+    _fields_ = [("n_inputs", C.c_int32), ("n_skip", C.c_int32), ("skip_index", C.POINTER(C.c_int32)),
+                ("n_mixers", C.c_int32), ("mixers", C.POINTER(MixerDesc))]
+
+
+def build(force=False):
+    """Compile libgmxmix.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-s", "-C", src, "clean"])
+    subprocess.check_call(["make", "-s", "-C", src, "all"])
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the HIP extension is the only implementation; nothing falls back to CPU)")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int, C.c_uint32
+    L.gmx_strerror.restype = C.c_char_p
+    L.gmx_strerror.argtypes = [i32]
+    L.gmx_last_error.restype = C.c_char_p
+    L.gmx_build_info.restype = C.c_char_p
+    L.gmx_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.gmx_group_create.argtypes = [C.POINTER(vp), C.POINTER(TopologyStruct), i32, i32]
+    L.gmx_group_destroy.argtypes = [vp]
+    L.gmx_group_destroy.restype = None
+    for f in (L.gmx_group_n_streams, L.gmx_group_n_mixers, L.gmx_group_n_inputs, L.gmx_group_reset,
+              L.gmx_group_sync):
+        f.argtypes = [vp]
+    L.gmx_group_bank_bytes.argtypes = [vp]
+    L.gmx_group_bank_bytes.restype = u64
+    L.gmx_bank_forward.argtypes = [vp, i32, vp, vp, i32, vp, C.POINTER(C.c_float), vp]
+    L.gmx_bank_learn.argtypes = [vp, i32, i32]
+    L.gmx_batch_create.argtypes = [C.POINTER(vp), vp, u64, C.c_uint]
+    L.gmx_batch_destroy.argtypes = [vp]
+    L.gmx_batch_destroy.restype = None
+    L.gmx_batch_n_pad.argtypes = [vp]
+    L.gmx_batch_mask_words.argtypes = [vp]
+    L.gmx_batch_max_bits.argtypes = [vp]
+    L.gmx_batch_max_bits.restype = u64
+    for name in ("gmx_batch_predictions", "gmx_batch_active_mask", "gmx_batch_contexts",
+                 "gmx_batch_bits", "gmx_batch_p", "gmx_batch_outputs"):
+        f = getattr(L, name)
+        f.argtypes = [vp]
+        f.restype = vp
+    L.gmx_batch_upload.argtypes = [vp, u64]
+    L.gmx_batch_download.argtypes = [vp, u64]
+    L.gmx_batch_wait.argtypes = [vp]
+    L.gmx_batch_fill_synthetic.argtypes = [vp, u64, u64, u64, i32, u32, u32, i32]
+    L.gmx_group_run.argtypes = [vp, vp, u64, i32, C.POINTER(C.c_float)]
+    L.gmx_bank_export.argtypes = [vp, i32, vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t)]
+    L.gmx_bank_import.argtypes = [vp, i32, vp, C.c_size_t, vp, C.c_size_t]
+    L.gmx_bank_copy.argtypes = [vp, i32, vp, i32]
+    L.gmx_bank_memory_usage.argtypes = [vp, i32, i32, C.POINTER(u64)]
+    L.gmx_debug_math_probe.argtypes = [i32, vp, vp, u64, i32]
+    L.gmx_debug_math_range.argtypes = [i32, u64, u64, i32, C.POINTER(C.c_ulonglong)]
+    _LIB = L
+    return L
+
+
+def check(status, where):
+    if status != 0:
+        raise GmxError(status, where)
+
+
+# Every symbol include/gmxmix.h declares; tests assert the built library exports them all.
+ABI_SYMBOLS = [
+    "gmx_strerror", "gmx_last_error", "gmx_device_count", "gmx_build_info", "gmx_group_create",
+    "gmx_group_destroy", "gmx_group_n_streams", "gmx_group_n_mixers", "gmx_group_n_inputs",
+    "gmx_group_bank_bytes", "gmx_group_reset", "gmx_group_sync", "gmx_bank_forward", "gmx_bank_learn",
+    "gmx_batch_create", "gmx_batch_destroy", "gmx_batch_n_pad", "gmx_batch_mask_words",
+    "gmx_batch_max_bits", "gmx_batch_predictions", "gmx_batch_active_mask", "gmx_batch_contexts",
+    "gmx_batch_bits", "gmx_batch_p", "gmx_batch_outputs", "gmx_batch_upload", "gmx_batch_download",
+    "gmx_batch_wait", "gmx_batch_fill_synthetic", "gmx_group_run", "gmx_bank_export",
+    "gmx_bank_import", "gmx_bank_copy", "gmx_bank_memory_usage",
+]

@@ -1,0 +1,848 @@
+// gmx_capi.cpp -- host side of libgmxmix.so: the C ABI of include/gmxmix.h.
+//
+// Owns device memory, the bank layout in HBM, record batches, the per-bit surface, and the
+// reference-compatible (de)serialisation.  No compute happens here: every Predict/Learn goes
+// to the gfx950 kernels of gmx_kernels.hip, and when no device is usable the calls fail with
+// GMX_ERR_NO_DEVICE -- there is no CPU fallback in the product path.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/gmxmix.h"
+#include "gmx_internal.h"
+
+struct GmxSynthArgs {
+  float* pred;
+  uint32_t* mask;
+  uint32_t* ctx;
+  uint8_t* bits;
+  uint64_t* rng;
+  uint64_t* tcount;
+  float* pstate;
+  uint32_t* cstate;
+  uint64_t rec_stride, n_bits, seed;
+  int32_t n, n_pad, m, mask_words, n_streams, restart, ctx_mode, bit_mode;
+  uint32_t ctx_mod, zero_mod;
+};
+
+extern "C" {
+hipError_t gmx_launch_bank_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_streams,
+                                  unsigned lds_bytes, int has_mask, hipStream_t stream);
+hipError_t gmx_bank_kernel_set_lds(unsigned lds_bytes);
+hipError_t gmx_launch_synth_kernel(const GmxSynthArgs* args, hipStream_t stream);
+hipError_t gmx_launch_init_scal(uint8_t* banks, uint64_t bank_bytes, uint64_t scal_off, int m,
+                                int n_streams, hipStream_t stream);
+hipError_t gmx_launch_math_probe(const float* x, float* y, uint64_t n, int what, hipStream_t stream);
+hipError_t gmx_launch_math_range(uint64_t lo, uint64_t count, int what, unsigned long long* out,
+                                 hipStream_t stream);
+}
+
+static thread_local std::string g_last_error;
+
+static int hip_fail(hipError_t e, const char* what) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+  g_last_error = buf;
+  (void)hipGetLastError();
+  return GMX_ERR_HIP;
+}
+#define HIPCHK(call)                                   \
+  do {                                                 \
+    hipError_t e_ = (call);                            \
+    if (e_ != hipSuccess) return hip_fail(e_, #call);  \
+  } while (0)
+
+struct gmx_group {
+  int device = 0;
+  int S = 0;
+  GmxTopoDev topo;                 // host copy
+  GmxTopoDev* topo_dev = nullptr;  // device copy
+  uint8_t* banks = nullptr;        // S * bank_bytes
+  float* latch_out = nullptr;      // [S][m]
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  unsigned lds_bytes = 0;
+  std::vector<uint64_t> steps;     // host mirror of Mixer::steps_ (identical for all mixers of a stream)
+  std::vector<uint8_t> fwd_done;   // per-bit protocol: forward seen, learn allowed
+  // decay tables staging
+  float* decay_dev = nullptr;
+  uint32_t* decay_idx_dev = nullptr;
+  float* decay_host = nullptr;     // pinned
+  uint32_t* decay_idx_host = nullptr;
+  size_t decay_cap = 0;            // floats
+  gmx_batch* one = nullptr;        // 1-bit batch (one record per stream) of the per-bit surface
+  std::vector<gmx_batch*> batches; // live batches; orphaned (b->g = nullptr) when the group dies
+};
+
+struct gmx_batch {
+  gmx_group* g = nullptr;
+  int S = 0;                       // streams covered (g->S, or 1 for the per-bit batch)
+  uint64_t max_bits = 0;
+  unsigned flags = 0;
+  // device
+  float* d_pred = nullptr;
+  uint32_t* d_mask = nullptr;
+  uint32_t* d_ctx = nullptr;
+  uint8_t* d_bits = nullptr;
+  float* d_p = nullptr;
+  float* d_out = nullptr;
+  // synthetic generator state
+  uint64_t* d_rng = nullptr;
+  uint64_t* d_tcount = nullptr;
+  float* d_pstate = nullptr;
+  uint32_t* d_cstate = nullptr;
+  // pinned host staging (lazy)
+  float* h_pred = nullptr;
+  uint32_t* h_mask = nullptr;
+  uint32_t* h_ctx = nullptr;
+  uint8_t* h_bits = nullptr;
+  float* h_p = nullptr;
+  float* h_out = nullptr;
+};
+
+extern "C" const char* gmx_strerror(int status) {
+  switch (status) {
+    case GMX_OK: return "ok";
+    case GMX_ERR_INVALID: return "invalid argument or unsupported topology";
+    case GMX_ERR_NOMEM: return "out of memory";
+    case GMX_ERR_HIP: return "HIP runtime error";
+    case GMX_ERR_NO_DEVICE: return "no usable gfx950 device (this library has no CPU fallback)";
+    case GMX_ERR_STATE: return "call order violated";
+    case GMX_ERR_FORMAT: return "malformed checkpoint";
+    default: return "unknown status";
+  }
+}
+
+extern "C" const char* gmx_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" const char* gmx_build_info(void) {
+  return "libgmxmix gfx950 (CDNA4) hipcc -O3 -ffp-contract=off; abi 1";
+}
+
+extern "C" int gmx_device_count(int* count) {
+  if (!count) return GMX_ERR_INVALID;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    *count = 0;
+    return GMX_OK;
+  }
+  *count = n;
+  return GMX_OK;
+}
+
+static uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+static uint64_t round_up64(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+// Predictor::AddMixers bookkeeping (predictor.cpp:251-358, mixer.cpp:3-27,
+// short-term-memory.cpp:199-213) turned into a device layout.
+static int build_topology(const gmx_topology* t, GmxTopoDev* o) {
+  if (!t || !t->mixers || t->n_mixers < 1 || t->n_mixers > GMX_MAX_MIXERS) return GMX_ERR_INVALID;
+  if (t->n_inputs < 1 || t->n_inputs > GMX_MAX_INPUTS) return GMX_ERR_INVALID;
+  if (t->n_skip < 0 || t->n_skip > GMX_MAX_SKIP || (t->n_skip > 0 && !t->skip_index))
+    return GMX_ERR_INVALID;
+  memset(o, 0, sizeof *o);
+  o->n = t->n_inputs;
+  o->n_pad = (int32_t)round_up((uint32_t)t->n_inputs, 4);
+  o->n_skip = t->n_skip;
+  o->m = t->n_mixers;
+  o->mask_words = (t->n_inputs + 31) / 32;
+  for (int i = 0; i < t->n_skip; ++i) {
+    if (t->skip_index[i] < 0 || t->skip_index[i] >= t->n_inputs) return GMX_ERR_INVALID;
+    o->skip_idx[i] = t->skip_index[i];
+  }
+  int prev_layer = 0;
+  for (int j = 0; j < t->n_mixers; ++j) {
+    const gmx_mixer_desc& md = t->mixers[j];
+    if (md.layer < prev_layer || md.layer > 2 || md.table_size == 0) return GMX_ERR_INVALID;
+    if (md.layer == 2 && o->has_final) return GMX_ERR_INVALID;  // a second final would overwrite the first
+    prev_layer = md.layer;
+    GmxMixerDev& x = o->mx[j];
+    x.table_size = md.table_size;
+    x.layer = md.layer;
+    x.lr = md.learning_rate;
+    if (md.layer == 0) {
+      x.out_index = o->l0++;
+      x.weight_size = (uint32_t)(o->n + x.out_index);
+    } else if (md.layer == 1) {
+      x.out_index = o->l1++;
+      x.weight_size = (uint32_t)(o->l0 + x.out_index + o->n_skip);
+    } else {
+      x.out_index = 0;
+      x.weight_size = (uint32_t)(o->l0 + o->l1 + o->n_skip);
+      o->has_final = 1;
+    }
+    if (x.weight_size == 0) return GMX_ERR_INVALID;
+    x.stride = round_up(x.weight_size, 32);
+    x.pitch = x.stride + 4;
+  }
+  if (o->l0 < 1) return GMX_ERR_INVALID;
+  for (int j = o->l0; j < o->m; ++j)
+    if (o->mx[j].weight_size > 64) return GMX_ERR_INVALID;  // layer-1/final rows: one lane per weight
+  // bank layout in HBM: weight tables, then row-step tables, then per-mixer scalars
+  uint64_t off = 0;
+  for (int j = 0; j < o->m; ++j) {
+    o->mx[j].w_off = off;
+    off += (uint64_t)o->mx[j].table_size * o->mx[j].stride * 4u;
+  }
+  for (int j = 0; j < o->m; ++j) {
+    o->mx[j].rs_off = off;
+    off += (uint64_t)o->mx[j].table_size * 8u;
+    off = round_up64(off, 128);
+  }
+  o->scal_off = off;
+  off += (uint64_t)o->m * 24u;
+  o->bank_bytes = round_up64(off, 256);
+  // LDS image of one wave (float offsets)
+  uint32_t l = 0;
+  o->lds_in0 = l;
+  o->in0_sz = round_up((uint32_t)o->n_pad + (uint32_t)o->l0 + 4u, 4);
+  l += 2 * o->in0_sz;
+  o->lds_o1 = l;
+  l += round_up((uint32_t)(o->l1 ? o->l1 : 1), 4);
+  o->lds_skip = l;
+  l += GMX_MAX_SKIP;
+  o->lds_misc = l;
+  l += 256;
+  for (int j = 0; j < o->m; ++j) {
+    o->mx[j].lds_off = l;
+    l += 2 * o->mx[j].pitch;
+  }
+  o->lds_total = l;
+  if ((uint64_t)o->lds_total * 4u > 160u * 1024u) return GMX_ERR_INVALID;
+  return GMX_OK;
+}
+
+static void batch_free(gmx_batch* b);
+static int batch_alloc(gmx_batch** out, gmx_group* g, int S, uint64_t max_bits, unsigned flags);
+
+extern "C" int gmx_group_create(gmx_group** out, const gmx_topology* topo, int n_streams, int device) {
+  if (!out || n_streams < 1) return GMX_ERR_INVALID;
+  *out = nullptr;
+  GmxTopoDev td;
+  int rc = build_topology(topo, &td);
+  if (rc) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return GMX_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) return GMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(device));
+  gmx_group* g = new (std::nothrow) gmx_group();
+  if (!g) return GMX_ERR_NOMEM;
+  g->device = device;
+  g->S = n_streams;
+  g->topo = td;
+  g->lds_bytes = td.lds_total * 4u;
+  g->steps.assign(n_streams, 0);
+  g->fwd_done.assign(n_streams, 0);
+#define GCHK(call)                                 \
+  do {                                             \
+    hipError_t e_ = (call);                        \
+    if (e_ != hipSuccess) {                        \
+      int r_ = hip_fail(e_, #call);                \
+      gmx_group_destroy(g);                        \
+      return e_ == hipErrorOutOfMemory ? GMX_ERR_NOMEM : r_; \
+    }                                              \
+  } while (0)
+  GCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+  GCHK(hipEventCreate(&g->ev0));
+  GCHK(hipEventCreate(&g->ev1));
+  GCHK(hipMalloc((void**)&g->topo_dev, sizeof(GmxTopoDev)));
+  GCHK(hipMemcpy(g->topo_dev, &g->topo, sizeof(GmxTopoDev), hipMemcpyHostToDevice));
+  GCHK(hipMalloc((void**)&g->banks, (size_t)n_streams * td.bank_bytes));
+  GCHK(hipMalloc((void**)&g->latch_out, (size_t)n_streams * td.m * sizeof(float)));
+  GCHK(hipMemsetAsync(g->latch_out, 0, (size_t)n_streams * td.m * sizeof(float), g->stream));
+  if (g->lds_bytes > 48u * 1024u) GCHK(gmx_bank_kernel_set_lds(g->lds_bytes));
+#undef GCHK
+  rc = gmx_group_reset(g);
+  if (rc) {
+    gmx_group_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return GMX_OK;
+}
+
+extern "C" void gmx_group_destroy(gmx_group* g) {
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  if (g->stream) (void)hipStreamSynchronize(g->stream);
+  if (g->one) {
+    batch_free(g->one);
+    g->one = nullptr;
+  }
+  // Batches outlive their group only as empty shells: they keep their buffers until
+  // gmx_batch_destroy, but every call on them fails with GMX_ERR_INVALID from now on.
+  for (gmx_batch* b : g->batches) b->g = nullptr;
+  g->batches.clear();
+  if (g->banks) (void)hipFree(g->banks);
+  if (g->latch_out) (void)hipFree(g->latch_out);
+  if (g->topo_dev) (void)hipFree(g->topo_dev);
+  if (g->decay_dev) (void)hipFree(g->decay_dev);
+  if (g->decay_idx_dev) (void)hipFree(g->decay_idx_dev);
+  if (g->decay_host) (void)hipHostFree(g->decay_host);
+  if (g->decay_idx_host) (void)hipHostFree(g->decay_idx_host);
+  if (g->ev0) (void)hipEventDestroy(g->ev0);
+  if (g->ev1) (void)hipEventDestroy(g->ev1);
+  if (g->stream) (void)hipStreamDestroy(g->stream);
+  delete g;
+}
+
+extern "C" int gmx_group_n_streams(const gmx_group* g) { return g ? g->S : GMX_ERR_INVALID; }
+extern "C" int gmx_group_n_mixers(const gmx_group* g) { return g ? g->topo.m : GMX_ERR_INVALID; }
+extern "C" int gmx_group_n_inputs(const gmx_group* g) { return g ? g->topo.n : GMX_ERR_INVALID; }
+extern "C" uint64_t gmx_group_bank_bytes(const gmx_group* g) { return g ? g->topo.bank_bytes : 0; }
+
+extern "C" int gmx_group_reset(gmx_group* g) {
+  if (!g) return GMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(g->device));
+  HIPCHK(hipMemsetAsync(g->banks, 0, (size_t)g->S * g->topo.bank_bytes, g->stream));
+  HIPCHK(gmx_launch_init_scal(g->banks, g->topo.bank_bytes, g->topo.scal_off, g->topo.m, g->S,
+                              g->stream));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  std::fill(g->steps.begin(), g->steps.end(), 0);
+  std::fill(g->fwd_done.begin(), g->fwd_done.end(), 0);
+  return GMX_OK;
+}
+
+extern "C" int gmx_group_sync(gmx_group* g) {
+  if (!g) return GMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(g->device));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  return GMX_OK;
+}
+
+// First factor of the learning-rate decay, float(0.9 / pow(1e-7 * steps_ + 0.8, 0.8))
+// (mixer.cpp:111).  It depends on the bit count only, so the host computes it once per bit
+// with the same libm pow the reference calls and ships it with the records; the per-row
+// second factor (mixer.cpp:112) is IEEE double arithmetic and stays on the device.
+static float decay_base(uint64_t steps) { return (float)(0.9 / pow(0.0000001 * steps + 0.8, 0.8)); }
+
+// Fill the group's decay tables for a run of T learning bits over streams [s0, s0+ns).
+static int prepare_decay(gmx_group* g, int s0, int ns, uint64_t T, int learn) {
+  std::map<uint64_t, uint32_t> uniq;
+  std::vector<uint32_t> idx(ns);
+  for (int i = 0; i < ns; ++i) {
+    uint64_t st = learn ? g->steps[s0 + i] : 0;
+    auto it = uniq.find(st);
+    if (it == uniq.end()) it = uniq.emplace(st, (uint32_t)uniq.size()).first;
+    idx[i] = it->second;
+  }
+  const size_t need = (size_t)uniq.size() * T + (size_t)ns;
+  if (need > g->decay_cap) {
+    // the previous run may still be reading the old tables
+    HIPCHK(hipStreamSynchronize(g->stream));
+    if (g->decay_dev) (void)hipFree(g->decay_dev);
+    if (g->decay_idx_dev) (void)hipFree(g->decay_idx_dev);
+    if (g->decay_host) (void)hipHostFree(g->decay_host);
+    if (g->decay_idx_host) (void)hipHostFree(g->decay_idx_host);
+    g->decay_dev = nullptr;
+    g->decay_idx_dev = nullptr;
+    g->decay_host = nullptr;
+    g->decay_idx_host = nullptr;
+    g->decay_cap = 0;
+    size_t cap = need + need / 2 + 1024;
+    HIPCHK(hipMalloc((void**)&g->decay_dev, cap * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&g->decay_idx_dev, cap * sizeof(uint32_t)));
+    HIPCHK(hipHostMalloc((void**)&g->decay_host, cap * sizeof(float), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&g->decay_idx_host, cap * sizeof(uint32_t), hipHostMallocDefault));
+    g->decay_cap = cap;
+  } else {
+    // pinned staging is reused: make sure the previous upload has been consumed
+    HIPCHK(hipStreamSynchronize(g->stream));
+  }
+  for (auto& kv : uniq) {
+    float* tab = g->decay_host + (size_t)kv.second * T;
+    if (learn)
+      for (uint64_t t = 0; t < T; ++t) tab[t] = decay_base(kv.first + t);
+    else
+      for (uint64_t t = 0; t < T; ++t) tab[t] = 0.f;
+  }
+  memcpy(g->decay_idx_host, idx.data(), ns * sizeof(uint32_t));
+  HIPCHK(hipMemcpyAsync(g->decay_dev, g->decay_host, uniq.size() * T * sizeof(float),
+                        hipMemcpyHostToDevice, g->stream));
+  HIPCHK(hipMemcpyAsync(g->decay_idx_dev, g->decay_idx_host, ns * sizeof(uint32_t),
+                        hipMemcpyHostToDevice, g->stream));
+  return GMX_OK;
+}
+
+static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint64_t T,
+                      unsigned mode, float* kernel_ms) {
+  if (T == 0) return GMX_OK;
+  int rc = prepare_decay(g, s0, ns, T, (mode & GMX_MODE_LEARN) ? 1 : 0);
+  if (rc) return rc;
+  GmxRunArgs a;
+  memset(&a, 0, sizeof a);
+  a.banks = g->banks;
+  a.pred = b->d_pred;
+  a.mask = (b->flags & GMX_BATCH_MASK) ? b->d_mask : nullptr;
+  a.ctx = b->d_ctx;
+  a.bits = b->d_bits;
+  a.decay = g->decay_dev;
+  a.decay_idx = g->decay_idx_dev;
+  a.p_out = b->d_p;
+  a.out_all = (b->flags & GMX_BATCH_OUTPUTS) ? b->d_out : nullptr;
+  a.latch_out = g->latch_out;
+  a.rec_stride = b->max_bits;
+  a.T = T;
+  a.mode = mode;
+  a.stream_base = s0;
+  a.rec_base = rec0;
+  if (kernel_ms) HIPCHK(hipEventRecord(g->ev0, g->stream));
+  HIPCHK(gmx_launch_bank_kernel(g->topo_dev, &a, ns, g->lds_bytes, a.mask != nullptr, g->stream));
+  if (kernel_ms) {
+    HIPCHK(hipEventRecord(g->ev1, g->stream));
+    HIPCHK(hipEventSynchronize(g->ev1));
+    HIPCHK(hipEventElapsedTime(kernel_ms, g->ev0, g->ev1));
+  }
+  if (mode & GMX_MODE_LEARN)
+    for (int i = 0; i < ns; ++i) g->steps[s0 + i] += T;
+  return GMX_OK;
+}
+
+// ---- batches ---------------------------------------------------------------------------
+static void batch_free(gmx_batch* b) {
+  if (!b) return;
+  if (b->g) {
+    (void)hipSetDevice(b->g->device);
+    if (b->g->stream) (void)hipStreamSynchronize(b->g->stream);
+    auto& v = b->g->batches;
+    v.erase(std::remove(v.begin(), v.end(), b), v.end());
+  }
+  void* dv[] = {b->d_pred, b->d_mask, b->d_ctx, b->d_bits, b->d_p, b->d_out,
+                b->d_rng, b->d_tcount, b->d_pstate, b->d_cstate};
+  for (void* p : dv)
+    if (p) (void)hipFree(p);
+  void* hv[] = {b->h_pred, b->h_mask, b->h_ctx, b->h_bits, b->h_p, b->h_out};
+  for (void* p : hv)
+    if (p) (void)hipHostFree(p);
+  delete b;
+}
+
+static int batch_alloc(gmx_batch** out, gmx_group* g, int S, uint64_t max_bits, unsigned flags) {
+  if (!out || !g || max_bits == 0) return GMX_ERR_INVALID;
+  *out = nullptr;
+  HIPCHK(hipSetDevice(g->device));
+  gmx_batch* b = new (std::nothrow) gmx_batch();
+  if (!b) return GMX_ERR_NOMEM;
+  b->g = g;
+  b->S = S;
+  b->max_bits = max_bits;
+  b->flags = flags;
+  const GmxTopoDev& t = g->topo;
+  const size_t R = (size_t)S * max_bits;
+#define BCHK(call)                                 \
+  do {                                             \
+    hipError_t e_ = (call);                        \
+    if (e_ != hipSuccess) {                        \
+      int r_ = hip_fail(e_, #call);                \
+      batch_free(b);                               \
+      return e_ == hipErrorOutOfMemory ? GMX_ERR_NOMEM : r_; \
+    }                                              \
+  } while (0)
+  BCHK(hipMalloc((void**)&b->d_pred, R * t.n_pad * sizeof(float)));
+  if (flags & GMX_BATCH_MASK) BCHK(hipMalloc((void**)&b->d_mask, R * t.mask_words * sizeof(uint32_t)));
+  BCHK(hipMalloc((void**)&b->d_ctx, R * t.m * sizeof(uint32_t)));
+  BCHK(hipMalloc((void**)&b->d_bits, R));
+  BCHK(hipMalloc((void**)&b->d_p, R * sizeof(float)));
+  if (flags & GMX_BATCH_OUTPUTS) BCHK(hipMalloc((void**)&b->d_out, R * t.m * sizeof(float)));
+#undef BCHK
+  g->batches.push_back(b);
+  *out = b;
+  return GMX_OK;
+}
+
+extern "C" int gmx_batch_create(gmx_batch** out, gmx_group* g, uint64_t max_bits, unsigned flags) {
+  if (!g) return GMX_ERR_INVALID;
+  return batch_alloc(out, g, g->S, max_bits, flags);
+}
+
+extern "C" void gmx_batch_destroy(gmx_batch* b) { batch_free(b); }
+extern "C" int gmx_batch_n_pad(const gmx_batch* b) { return (b && b->g) ? b->g->topo.n_pad : GMX_ERR_INVALID; }
+extern "C" int gmx_batch_mask_words(const gmx_batch* b) { return (b && b->g) ? b->g->topo.mask_words : GMX_ERR_INVALID; }
+extern "C" uint64_t gmx_batch_max_bits(const gmx_batch* b) { return b ? b->max_bits : 0; }
+
+template <typename T>
+static T* lazy_host(gmx_batch* b, T** slot, size_t count) {
+  if (!*slot) {
+    if (hipSetDevice(b->g->device) != hipSuccess) return nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, count * sizeof(T), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    memset(p, 0, count * sizeof(T));
+    *slot = (T*)p;
+  }
+  return *slot;
+}
+
+extern "C" float* gmx_batch_predictions(gmx_batch* b) {
+  return (b && b->g) ? lazy_host(b, &b->h_pred, (size_t)b->S * b->max_bits * b->g->topo.n_pad) : nullptr;
+}
+extern "C" uint32_t* gmx_batch_active_mask(gmx_batch* b) {
+  if (!b || !b->g || !(b->flags & GMX_BATCH_MASK)) return nullptr;
+  return lazy_host(b, &b->h_mask, (size_t)b->S * b->max_bits * b->g->topo.mask_words);
+}
+extern "C" uint32_t* gmx_batch_contexts(gmx_batch* b) {
+  return (b && b->g) ? lazy_host(b, &b->h_ctx, (size_t)b->S * b->max_bits * b->g->topo.m) : nullptr;
+}
+extern "C" uint8_t* gmx_batch_bits(gmx_batch* b) {
+  return (b && b->g) ? lazy_host(b, &b->h_bits, (size_t)b->S * b->max_bits) : nullptr;
+}
+extern "C" const float* gmx_batch_p(gmx_batch* b) {
+  return (b && b->g) ? lazy_host(b, &b->h_p, (size_t)b->S * b->max_bits) : nullptr;
+}
+extern "C" const float* gmx_batch_outputs(gmx_batch* b) {
+  if (!b || !b->g || !(b->flags & GMX_BATCH_OUTPUTS)) return nullptr;
+  return lazy_host(b, &b->h_out, (size_t)b->S * b->max_bits * b->g->topo.m);
+}
+
+// Copy the first n_bits records of every stream (rows of a [S][max_bits][w] array).
+static hipError_t copy_rows(void* dst, const void* src, size_t elem_bytes, size_t w, gmx_batch* b,
+                            uint64_t n_bits, hipMemcpyKind kind) {
+  const size_t pitch = (size_t)b->max_bits * w * elem_bytes;
+  const size_t width = (size_t)n_bits * w * elem_bytes;
+  if (n_bits == b->max_bits || b->S == 1)
+    return hipMemcpyAsync(dst, src, b->S == 1 ? width : pitch * b->S, kind, b->g->stream);
+  return hipMemcpy2DAsync(dst, pitch, src, pitch, width, (size_t)b->S, kind, b->g->stream);
+}
+
+extern "C" int gmx_batch_upload(gmx_batch* b, uint64_t n_bits) {
+  if (!b || !b->g || n_bits > b->max_bits) return GMX_ERR_INVALID;
+  if (n_bits == 0) return GMX_OK;
+  const GmxTopoDev& t = b->g->topo;
+  HIPCHK(hipSetDevice(b->g->device));
+  if (!gmx_batch_predictions(b) || !gmx_batch_contexts(b) || !gmx_batch_bits(b)) return GMX_ERR_NOMEM;
+  HIPCHK(copy_rows(b->d_pred, b->h_pred, 4, t.n_pad, b, n_bits, hipMemcpyHostToDevice));
+  if (b->flags & GMX_BATCH_MASK) {
+    if (!gmx_batch_active_mask(b)) return GMX_ERR_NOMEM;
+    HIPCHK(copy_rows(b->d_mask, b->h_mask, 4, t.mask_words, b, n_bits, hipMemcpyHostToDevice));
+  }
+  HIPCHK(copy_rows(b->d_ctx, b->h_ctx, 4, t.m, b, n_bits, hipMemcpyHostToDevice));
+  HIPCHK(copy_rows(b->d_bits, b->h_bits, 1, 1, b, n_bits, hipMemcpyHostToDevice));
+  return GMX_OK;
+}
+
+extern "C" int gmx_batch_download(gmx_batch* b, uint64_t n_bits) {
+  if (!b || !b->g || n_bits > b->max_bits) return GMX_ERR_INVALID;
+  if (n_bits == 0) return GMX_OK;
+  const GmxTopoDev& t = b->g->topo;
+  HIPCHK(hipSetDevice(b->g->device));
+  if (!gmx_batch_p(b)) return GMX_ERR_NOMEM;
+  HIPCHK(copy_rows(b->h_p, b->d_p, 4, 1, b, n_bits, hipMemcpyDeviceToHost));
+  if (b->flags & GMX_BATCH_OUTPUTS) {
+    if (!gmx_batch_outputs(b)) return GMX_ERR_NOMEM;
+    HIPCHK(copy_rows(b->h_out, b->d_out, 4, t.m, b, n_bits, hipMemcpyDeviceToHost));
+  }
+  return GMX_OK;
+}
+
+extern "C" int gmx_batch_wait(gmx_batch* b) {
+  if (!b || !b->g) return GMX_ERR_INVALID;
+  return gmx_group_sync(b->g);
+}
+
+extern "C" int gmx_batch_fill_synthetic(gmx_batch* b, uint64_t n_bits, uint64_t seed,
+                                        uint64_t restart, int ctx_mode, uint32_t ctx_mod,
+                                        uint32_t zero_mod, int bit_mode) {
+  if (!b || !b->g || n_bits > b->max_bits) return GMX_ERR_INVALID;
+  const GmxTopoDev& t = b->g->topo;
+  HIPCHK(hipSetDevice(b->g->device));
+  if (!b->d_rng) {
+    if (!restart) return GMX_ERR_STATE;
+    HIPCHK(hipMalloc((void**)&b->d_rng, (size_t)b->S * 8));
+    HIPCHK(hipMalloc((void**)&b->d_tcount, (size_t)b->S * 8));
+    HIPCHK(hipMalloc((void**)&b->d_pstate, (size_t)b->S * t.n_pad * 4));
+    HIPCHK(hipMalloc((void**)&b->d_cstate, (size_t)b->S * t.m * 4));
+  }
+  GmxSynthArgs a;
+  memset(&a, 0, sizeof a);
+  a.pred = b->d_pred;
+  a.mask = (b->flags & GMX_BATCH_MASK) ? b->d_mask : nullptr;
+  a.ctx = b->d_ctx;
+  a.bits = b->d_bits;
+  a.rng = b->d_rng;
+  a.tcount = b->d_tcount;
+  a.pstate = b->d_pstate;
+  a.cstate = b->d_cstate;
+  a.rec_stride = b->max_bits;
+  a.n_bits = n_bits;
+  a.seed = seed ? seed : 0x9E3779B97F4A7C15ull;
+  a.n = t.n;
+  a.n_pad = t.n_pad;
+  a.m = t.m;
+  a.mask_words = t.mask_words;
+  a.n_streams = b->S;
+  a.restart = restart ? 1 : 0;
+  a.ctx_mode = ctx_mode;
+  a.bit_mode = bit_mode;
+  a.ctx_mod = ctx_mod;
+  a.zero_mod = zero_mod;
+  HIPCHK(gmx_launch_synth_kernel(&a, b->g->stream));
+  return GMX_OK;
+}
+
+extern "C" int gmx_group_run(gmx_group* g, gmx_batch* b, uint64_t n_bits, int learn, float* kernel_ms) {
+  if (!g || !b || b->g != g || b->S != g->S || n_bits > b->max_bits) return GMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(g->device));
+  std::fill(g->fwd_done.begin(), g->fwd_done.end(), 0);
+  return launch_run(g, b, 0, 0, g->S, n_bits, GMX_MODE_PREDICT | (learn ? GMX_MODE_LEARN : 0u),
+                    kernel_ms);
+}
+
+// ---- per-bit surface -------------------------------------------------------------------
+// One 1-bit record per stream lives in g->one (a batch with max_bits = 1 over all streams):
+// forward writes stream s's record and latches its outputs, learn re-reads both.
+static int ensure_one(gmx_group* g) {
+  if (g->one) return GMX_OK;
+  int rc = batch_alloc(&g->one, g, g->S, 1, GMX_BATCH_OUTPUTS | GMX_BATCH_MASK);
+  if (rc) return rc;
+  if (!gmx_batch_predictions(g->one) || !gmx_batch_active_mask(g->one) || !gmx_batch_contexts(g->one) ||
+      !gmx_batch_bits(g->one) || !gmx_batch_p(g->one) || !gmx_batch_outputs(g->one))
+    return GMX_ERR_NOMEM;
+  return GMX_OK;
+}
+
+extern "C" int gmx_bank_forward(gmx_group* g, int stream, const float* predictions,
+                                const int32_t* active_models, int n_active, const uint32_t* contexts,
+                                float* p_final, float* out_all) {
+  if (!g || stream < 0 || stream >= g->S || !predictions || !contexts) return GMX_ERR_INVALID;
+  if (n_active > 0 && !active_models) return GMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(g->device));
+  int rc = ensure_one(g);
+  if (rc) return rc;
+  gmx_batch* b = g->one;
+  const GmxTopoDev& t = g->topo;
+  const size_t s = (size_t)stream;
+  HIPCHK(hipStreamSynchronize(g->stream));
+  float* hp = b->h_pred + s * t.n_pad;
+  uint32_t* hm = b->h_mask + s * t.mask_words;
+  uint32_t* hc = b->h_ctx + s * t.m;
+  memcpy(hp, predictions, t.n * sizeof(float));
+  for (int i = t.n; i < t.n_pad; ++i) hp[i] = 0.f;
+  if (n_active < 0) {
+    for (int w = 0; w < t.mask_words; ++w) hm[w] = 0xffffffffu;
+  } else {
+    for (int w = 0; w < t.mask_words; ++w) hm[w] = 0;
+    for (int i = 0; i < n_active; ++i) {
+      int idx = active_models[i];
+      if (idx < 0 || idx >= t.n) return GMX_ERR_INVALID;
+      hm[idx >> 5] |= 1u << (idx & 31);
+    }
+  }
+  memcpy(hc, contexts, t.m * sizeof(uint32_t));
+  HIPCHK(hipMemcpyAsync(b->d_pred + s * t.n_pad, hp, t.n_pad * 4, hipMemcpyHostToDevice, g->stream));
+  HIPCHK(hipMemcpyAsync(b->d_mask + s * t.mask_words, hm, t.mask_words * 4, hipMemcpyHostToDevice,
+                        g->stream));
+  HIPCHK(hipMemcpyAsync(b->d_ctx + s * t.m, hc, t.m * 4, hipMemcpyHostToDevice, g->stream));
+  rc = launch_run(g, b, stream, stream, 1, 1, GMX_MODE_PREDICT | GMX_MODE_LATCH, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(b->h_p + s, b->d_p + s, 4, hipMemcpyDeviceToHost, g->stream));
+  if (out_all)
+    HIPCHK(hipMemcpyAsync(b->h_out + s * t.m, b->d_out + s * t.m, t.m * 4, hipMemcpyDeviceToHost,
+                          g->stream));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  if (p_final) *p_final = b->h_p[s];
+  if (out_all) memcpy(out_all, b->h_out + s * t.m, t.m * sizeof(float));
+  g->fwd_done[stream] = 1;
+  return GMX_OK;
+}
+
+extern "C" int gmx_bank_learn(gmx_group* g, int stream, int bit) {
+  if (!g || stream < 0 || stream >= g->S || (bit != 0 && bit != 1)) return GMX_ERR_INVALID;
+  if (!g->one || !g->fwd_done[stream]) return GMX_ERR_STATE;
+  HIPCHK(hipSetDevice(g->device));
+  gmx_batch* b = g->one;
+  HIPCHK(hipStreamSynchronize(g->stream));
+  b->h_bits[stream] = (uint8_t)bit;
+  HIPCHK(hipMemcpyAsync(b->d_bits + stream, b->h_bits + stream, 1, hipMemcpyHostToDevice, g->stream));
+  int rc = launch_run(g, b, stream, stream, 1, 1, GMX_MODE_LEARN, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(g->stream));
+  g->fwd_done[stream] = 0;
+  return GMX_OK;
+}
+
+// ---- persistence -------------------------------------------------------------------------
+static int fetch_bank(gmx_group* g, int stream, std::vector<uint8_t>& img) {
+  img.resize(g->topo.bank_bytes);
+  HIPCHK(hipSetDevice(g->device));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  HIPCHK(hipMemcpy(img.data(), g->banks + (size_t)stream * g->topo.bank_bytes, img.size(),
+                   hipMemcpyDeviceToHost));
+  return GMX_OK;
+}
+
+extern "C" int gmx_bank_export(gmx_group* g, int stream, void* long_buf, size_t* long_bytes,
+                               void* short_buf, size_t* short_bytes) {
+  if (!g || stream < 0 || stream >= g->S || !long_bytes || !short_bytes) return GMX_ERR_INVALID;
+  const GmxTopoDev& t = g->topo;
+  std::vector<uint8_t> img;
+  int rc = fetch_bank(g, stream, img);
+  if (rc) return rc;
+  // Mixer::WriteToDisk x m (mixer.cpp:178-182)
+  const size_t need_short = (size_t)t.m * 24;
+  // mixer section of LongTermMemory::WriteToDisk (long-term-memory.cpp:35-55)
+  size_t need_long = 0;
+  for (int j = 0; j < t.m; ++j) {
+    const uint64_t* rs = (const uint64_t*)(img.data() + t.mx[j].rs_off);
+    need_long += 8;
+    for (uint32_t r = 0; r < t.mx[j].table_size; ++r)
+      if (rs[r]) need_long += 12 + 4 * (size_t)t.mx[j].weight_size;
+  }
+  const bool fits = long_buf && short_buf && *long_bytes >= need_long && *short_bytes >= need_short;
+  *long_bytes = need_long;
+  *short_bytes = need_short;
+  if (!long_buf && !short_buf) return GMX_OK;
+  if (!fits) return GMX_ERR_INVALID;
+  memcpy(short_buf, img.data() + t.scal_off, need_short);
+  uint8_t* o = (uint8_t*)long_buf;
+  for (int j = 0; j < t.m; ++j) {
+    const GmxMixerDev& x = t.mx[j];
+    const uint64_t* rs = (const uint64_t*)(img.data() + x.rs_off);
+    const float* w = (const float*)(img.data() + x.w_off);
+    uint32_t cnt = 0;
+    for (uint32_t r = 0; r < x.table_size; ++r)
+      if (rs[r]) ++cnt;
+    uint32_t input_size = cnt ? x.weight_size : 0;
+    memcpy(o, &cnt, 4);
+    memcpy(o + 4, &input_size, 4);
+    o += 8;
+    for (uint32_t r = 0; r < x.table_size; ++r) {
+      if (!rs[r]) continue;
+      memcpy(o, &r, 4);
+      memcpy(o + 4, &rs[r], 8);
+      memcpy(o + 12, w + (size_t)r * x.stride, 4 * (size_t)x.weight_size);
+      o += 12 + 4 * (size_t)x.weight_size;
+    }
+  }
+  return GMX_OK;
+}
+
+extern "C" int gmx_bank_import(gmx_group* g, int stream, const void* long_buf, size_t long_bytes,
+                               const void* short_buf, size_t short_bytes) {
+  if (!g || stream < 0 || stream >= g->S || !long_buf || !short_buf) return GMX_ERR_INVALID;
+  const GmxTopoDev& t = g->topo;
+  if (short_bytes != (size_t)t.m * 24) return GMX_ERR_FORMAT;
+  std::vector<uint8_t> img(t.bank_bytes, 0);
+  memcpy(img.data() + t.scal_off, short_buf, short_bytes);
+  const uint64_t* sc = (const uint64_t*)(img.data() + t.scal_off);
+  for (int j = 1; j < t.m; ++j)
+    if (sc[3 * j] != sc[0]) return GMX_ERR_FORMAT;  // every Mixer learns on every bit: steps_ agree
+  // LongTermMemory::ReadFromDisk, mixer section (long-term-memory.cpp:134-149)
+  const uint8_t* p = (const uint8_t*)long_buf;
+  const uint8_t* end = p + long_bytes;
+  for (int j = 0; j < t.m; ++j) {
+    const GmxMixerDev& x = t.mx[j];
+    if (end - p < 8) return GMX_ERR_FORMAT;
+    uint32_t cnt, input_size;
+    memcpy(&cnt, p, 4);
+    memcpy(&input_size, p + 4, 4);
+    p += 8;
+    if (cnt > x.table_size || (cnt && input_size != x.weight_size)) return GMX_ERR_FORMAT;
+    uint64_t* rs = (uint64_t*)(img.data() + x.rs_off);
+    float* w = (float*)(img.data() + x.w_off);
+    for (uint32_t i = 0; i < cnt; ++i) {
+      if ((size_t)(end - p) < 12 + 4 * (size_t)input_size) return GMX_ERR_FORMAT;
+      uint32_t r;
+      memcpy(&r, p, 4);
+      if (r >= x.table_size) return GMX_ERR_FORMAT;
+      memcpy(&rs[r], p + 4, 8);
+      if (rs[r] == 0) return GMX_ERR_FORMAT;  // a stored row has been learned at least once
+      memcpy(w + (size_t)r * x.stride, p + 12, 4 * (size_t)input_size);
+      p += 12 + 4 * (size_t)input_size;
+    }
+  }
+  if (p != end) return GMX_ERR_FORMAT;
+  HIPCHK(hipSetDevice(g->device));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  HIPCHK(hipMemcpy(g->banks + (size_t)stream * t.bank_bytes, img.data(), img.size(),
+                   hipMemcpyHostToDevice));
+  g->steps[stream] = sc[0];
+  g->fwd_done[stream] = 0;
+  return GMX_OK;
+}
+
+extern "C" int gmx_bank_copy(gmx_group* dst, int dst_stream, gmx_group* src, int src_stream) {
+  if (!dst || !src || dst_stream < 0 || dst_stream >= dst->S || src_stream < 0 || src_stream >= src->S)
+    return GMX_ERR_INVALID;
+  const GmxTopoDev &a = dst->topo, &b = src->topo;
+  if (a.m != b.m || a.n != b.n || a.n_skip != b.n_skip || a.bank_bytes != b.bank_bytes)
+    return GMX_ERR_INVALID;
+  for (int j = 0; j < a.m; ++j)
+    if (a.mx[j].table_size != b.mx[j].table_size || a.mx[j].weight_size != b.mx[j].weight_size ||
+        a.mx[j].layer != b.mx[j].layer)
+      return GMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(src->device));
+  HIPCHK(hipStreamSynchronize(src->stream));
+  HIPCHK(hipSetDevice(dst->device));
+  HIPCHK(hipStreamSynchronize(dst->stream));
+  HIPCHK(hipMemcpy(dst->banks + (size_t)dst_stream * a.bank_bytes,
+                   src->banks + (size_t)src_stream * b.bank_bytes, a.bank_bytes,
+                   hipMemcpyDeviceToDevice));
+  dst->steps[dst_stream] = src->steps[src_stream];
+  dst->fwd_done[dst_stream] = 0;
+  return GMX_OK;
+}
+
+extern "C" int gmx_bank_memory_usage(gmx_group* g, int stream, int mixer, uint64_t* bytes) {
+  if (!g || stream < 0 || stream >= g->S || mixer < 0 || mixer >= g->topo.m || !bytes)
+    return GMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(g->device));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  uint64_t sc[3];
+  HIPCHK(hipMemcpy(sc, g->banks + (size_t)stream * g->topo.bank_bytes + g->topo.scal_off + 24u * mixer,
+                   24, hipMemcpyDeviceToHost));
+  // Mixer::GetMemoryUsage (mixer.cpp:197-205)
+  const GmxMixerDev& x = g->topo.mx[mixer];
+  *bytes = 29 + sc[2] * (uint64_t)(x.weight_size * 4 + 12) + 8ull * x.table_size;
+  return GMX_OK;
+}
+
+// ---- test probes (device math against host math; not part of the product surface) --------
+extern "C" int gmx_debug_math_probe(int device, const float* x, float* y, uint64_t n, int what) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return GMX_ERR_NO_DEVICE;
+  }
+  HIPCHK(hipSetDevice(device));
+  float *dx = nullptr, *dy = nullptr;
+  HIPCHK(hipMalloc((void**)&dx, n * 4));
+  HIPCHK(hipMalloc((void**)&dy, n * 4));
+  HIPCHK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+  HIPCHK(gmx_launch_math_probe(dx, dy, n, what, nullptr));
+  HIPCHK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(dx);
+  (void)hipFree(dy);
+  return GMX_OK;
+}
+
+extern "C" int gmx_debug_math_range(int device, uint64_t lo, uint64_t count, int what,
+                                    unsigned long long out[2]) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return GMX_ERR_NO_DEVICE;
+  }
+  HIPCHK(hipSetDevice(device));
+  unsigned long long* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, 16));
+  HIPCHK(hipMemset(d, 0, 16));
+  HIPCHK(gmx_launch_math_range(lo, count, what, d, nullptr));
+  HIPCHK(hipMemcpy(out, d, 16, hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return GMX_OK;
+}

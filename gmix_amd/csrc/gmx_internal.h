@@ -1,0 +1,62 @@
+// gmx_internal.h -- structures shared by the host side of libgmxmix.so and its kernels.
+#ifndef GMX_INTERNAL_H_
+#define GMX_INTERNAL_H_
+
+#include <stdint.h>
+
+#define GMX_MAX_MIXERS 64
+#define GMX_MAX_SKIP 8
+#define GMX_MAX_INPUTS 2048
+
+#define GMX_MODE_PREDICT 1u   // run the forward chain (else: outputs come from the latch)
+#define GMX_MODE_LEARN 2u     // run Mixer::Learn after each bit
+#define GMX_MODE_LATCH 4u     // forward-only call of the per-bit surface: keep outputs for learn
+
+// Device-side description of one Mixer (mixer.h:33-38 + where its table lives in a bank).
+struct GmxMixerDev {
+  uint32_t table_size;   // rows of the gate table (mixer.cpp:15)
+  uint32_t weight_size;  // weight_size_ (mixer.cpp:17-26)
+  uint32_t stride;       // floats per stored row: weight_size rounded up to 32 (128-B rows)
+  uint32_t lds_off;      // float offset of this mixer's slot 0 in the wave's LDS image
+  uint32_t pitch;        // float distance between the mixer's two LDS slots (stride + 4)
+  int32_t layer;         // 0, 1, 2
+  int32_t out_index;     // index inside its layer (output_index_ for layers 0/1)
+  float lr;              // learning_rate_
+  uint64_t w_off;        // byte offset of the weight table inside a bank
+  uint64_t rs_off;       // byte offset of the per-row step counters (MixerData::steps)
+};
+
+struct GmxTopoDev {
+  int32_t n, n_pad, n_skip, m, l0, l1, has_final, mask_words;
+  int32_t skip_idx[GMX_MAX_SKIP];
+  uint32_t lds_in0;      // float offset of in0[2][in0_sz]: [x (n) | layer-0 outputs (l0)]
+  uint32_t in0_sz;
+  uint32_t lds_o1;       // layer-1 outputs [l1]
+  uint32_t lds_skip;     // raw skip inputs [n_skip]
+  uint32_t lds_misc;     // per-mixer scratch: 4 x 64 dwords (row, dst slot, update, flags)
+  uint32_t lds_total;    // floats
+  uint64_t scal_off;     // byte offset of {steps_, max_steps_, contexts_seen_} x m
+  uint64_t bank_bytes;   // bytes per stream
+  GmxMixerDev mx[GMX_MAX_MIXERS];
+};
+
+// Kernel arguments of one run over T bits of `n_streams` streams.
+struct GmxRunArgs {
+  uint8_t* banks;             // device base of bank 0
+  const float* pred;          // [S][*][n_pad]
+  const uint32_t* mask;       // [S][*][mask_words] or null
+  const uint32_t* ctx;        // [S][*][m]
+  const uint8_t* bits;        // [S][*]
+  const float* decay;         // [n_tabs][T] first factor of the decay (mixer.cpp:111), host pow
+  const uint32_t* decay_idx;  // [S] which table a stream uses
+  float* p_out;               // [S][*]
+  float* out_all;             // [S][*][m] or null
+  float* latch_out;           // [S][m] outputs kept between forward and learn of the per-bit API
+  uint64_t rec_stride;        // records per stream in the arrays above (max_bits of the batch)
+  uint64_t T;
+  uint32_t mode;
+  int32_t stream_base;        // bank of block 0
+  int32_t rec_base;           // record-array stream index of block 0
+};
+
+#endif  // GMX_INTERNAL_H_

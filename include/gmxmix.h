@@ -1,0 +1,163 @@
+/* gmxmix.h -- C ABI of libgmxmix.so: gmix's mixer hot path on AMD MI355X (gfx950).
+ *
+ * This is the drop-in boundary for ONE path of byronknoll/gmix: the per-bit mixer (the 33
+ * `Mixer` objects that `Predictor::AddMixers` builds and that `Predictor::Predict()` /
+ * `Perceive()` / `Learn()` run after the feature models).  Everything else in gmix -- the
+ * context models, the arithmetic coder, the CLI -- stays on the host and is not part of this
+ * library.  Citations are file:line in the reference tree (/root/reference).
+ *
+ * Object model
+ *   gmx_group : S independent mixer banks ("streams") of one topology on one device.  One
+ *               bank = everything the last 33 entries of Predictor::models_ own: the
+ *               LongTermMemory::mixers tables (long-term-memory.h:27-40) plus each Mixer's
+ *               steps_/max_steps_/contexts_seen_ (mixer.h:33-38).  S = 1 is the drop-in for a
+ *               single Predictor; S > 1 is the embarrassingly parallel multi-file case.
+ *   gmx_batch : pinned host staging + device buffers for up to max_bits bits of per-stream
+ *               records {predictions[N], active mask, contexts[M], bit} and the results.
+ *
+ * Conventions
+ *   - every function returns 0 (GMX_OK) or a negative gmx_status; nothing throws or aborts
+ *     across this boundary (the reference's Model methods are void and never fail,
+ *     model.h:22-37; HIP failures are mapped to GMX_ERR_HIP and the text kept for
+ *     gmx_last_error()).
+ *   - a group is bound to one HIP stream and is not thread-safe (the reference Predictor is
+ *     single-threaded and not re-entrant); distinct groups are independent.
+ *   - results are a pure function of (bank state, inputs): the batched and the per-bit entry
+ *     points produce identical floats (the encoder/decoder symmetry the reference's tester
+ *     relies on, tester.cpp:350-356).
+ *   - arithmetic parity: every mixer output, probability, weight and counter equals what the
+ *     reference's strict C++ build computes, bit for bit (fp32 left-to-right sums, separate
+ *     multiply and add roundings, IEEE divide, glibc's expf restated in gmx_math.h).
+ */
+#ifndef GMXMIX_H_
+#define GMXMIX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gmx_status {
+  GMX_OK = 0,
+  GMX_ERR_INVALID = -1,      /* bad argument / unsupported topology */
+  GMX_ERR_NOMEM = -2,        /* host or device allocation failed */
+  GMX_ERR_HIP = -3,          /* a HIP runtime call failed; see gmx_last_error() */
+  GMX_ERR_NO_DEVICE = -4,    /* no usable gfx950 device: there is no CPU fallback */
+  GMX_ERR_STATE = -5,        /* call order violated (e.g. learn without forward) */
+  GMX_ERR_FORMAT = -6        /* malformed checkpoint bytes on import */
+} gmx_status;
+
+/* One Mixer constructor call (mixer.h:17-19; the literals of predictor.cpp:251-358):
+ * layer 0/1/2, gate-table size (rows), learning rate (the reference narrows a double
+ * literal to float at the call).  The gate context itself is per-bit data. */
+typedef struct gmx_mixer_desc {
+  int32_t layer;
+  uint32_t table_size;
+  float learning_rate;
+} gmx_mixer_desc;
+
+/* What Predictor's constructor fixes before AddMixers runs (predictor.cpp:17-40):
+ * num_predictions, models_with_skip_connection (lstm-model.cpp:12-14) and the mixers in
+ * construction order: all layer-0 mixers, then layer-1, then at most one final mixer.
+ * Limits: n_mixers <= 64, n_skip <= 8, n_inputs <= 2048,
+ * layer-1 and final rows <= 64 weights. */
+typedef struct gmx_topology {
+  int32_t n_inputs;
+  int32_t n_skip;
+  const int32_t* skip_index;     /* [n_skip] indices into predictions */
+  int32_t n_mixers;
+  const gmx_mixer_desc* mixers;  /* [n_mixers] */
+} gmx_topology;
+
+typedef struct gmx_group gmx_group;
+typedef struct gmx_batch gmx_batch;
+
+/* ---- library ------------------------------------------------------------------------ */
+const char* gmx_strerror(int status);
+const char* gmx_last_error(void);          /* text of the last GMX_ERR_HIP on this thread */
+int gmx_device_count(int* count);          /* gfx950 devices visible */
+const char* gmx_build_info(void);          /* arch, flags, version */
+
+/* ---- group: replaces Predictor::AddMixers' 33 objects (predictor.cpp:251-358) ---------- */
+int gmx_group_create(gmx_group** out, const gmx_topology* topo, int n_streams, int device);
+void gmx_group_destroy(gmx_group* g);
+int gmx_group_n_streams(const gmx_group* g);
+int gmx_group_n_mixers(const gmx_group* g);
+int gmx_group_n_inputs(const gmx_group* g);
+uint64_t gmx_group_bank_bytes(const gmx_group* g);   /* device bytes per stream */
+int gmx_group_reset(gmx_group* g);                   /* all banks back to the constructed state */
+int gmx_group_sync(gmx_group* g);                    /* wait for everything queued on its stream */
+
+/* ---- per-bit surface: Predict / Perceive / Learn for one stream ------------------------ */
+/* 33 x Mixer::Predict + the final squash of Predictor::Predict (mixer.cpp:51-106,
+ * predictor.cpp:366-375).  predictions[n_inputs] is the raw ShortTermMemory::predictions
+ * blackboard (stale slots allowed), active_models[n_active] the ascending model indices of
+ * ShortTermMemory::active_models (NULL with n_active < 0 = every slot active), contexts[M]
+ * the values of the context variables the mixers alias (mixer.h:31) read at call time.
+ * *p_final receives the clamped probability; out_all (nullable) the M logit outputs
+ * (mixer_layer0_outputs, mixer_layer1_outputs, final_mixer_output). Synchronous. */
+int gmx_bank_forward(gmx_group* g, int stream, const float* predictions,
+                     const int32_t* active_models, int n_active, const uint32_t* contexts,
+                     float* p_final, float* out_all);
+/* Predictor::Perceive(bit) + 33 x Mixer::Learn (predictor.cpp:378-387, mixer.cpp:108-176)
+ * on the inputs latched by the preceding gmx_bank_forward of that stream.  Optional, like
+ * Learn() in the reference (generation never calls it, runner-utils.cpp:199-209). */
+int gmx_bank_learn(gmx_group* g, int stream, int bit);
+
+/* ---- batched surface: T bits for every stream in one launch ---------------------------- */
+#define GMX_BATCH_OUTPUTS 1u   /* also return all M mixer outputs per bit */
+#define GMX_BATCH_MASK 2u      /* records carry an active mask; otherwise every slot is active */
+int gmx_batch_create(gmx_batch** out, gmx_group* g, uint64_t max_bits, unsigned flags);
+void gmx_batch_destroy(gmx_batch* b);
+/* Layout of the staging arrays (all stream-major, then bit):
+ *   predictions [S][max_bits][n_pad]   n_pad = n_inputs rounded up to 4 (gmx_batch_n_pad)
+ *   active_mask [S][max_bits][mask_words] bit i of word i/32 = model i is in active_models
+ *   contexts    [S][max_bits][M]
+ *   bits        [S][max_bits]
+ *   p           [S][max_bits]          clamped probabilities (what Predict() returns)
+ *   outputs     [S][max_bits][M]       with GMX_BATCH_OUTPUTS */
+int gmx_batch_n_pad(const gmx_batch* b);
+int gmx_batch_mask_words(const gmx_batch* b);
+uint64_t gmx_batch_max_bits(const gmx_batch* b);
+float* gmx_batch_predictions(gmx_batch* b);     /* pinned host pointers, caller fills/reads */
+uint32_t* gmx_batch_active_mask(gmx_batch* b);  /* NULL without GMX_BATCH_MASK */
+uint32_t* gmx_batch_contexts(gmx_batch* b);
+uint8_t* gmx_batch_bits(gmx_batch* b);
+const float* gmx_batch_p(gmx_batch* b);
+const float* gmx_batch_outputs(gmx_batch* b);   /* NULL without GMX_BATCH_OUTPUTS */
+int gmx_batch_upload(gmx_batch* b, uint64_t n_bits);    /* async H2D of the first n_bits of every stream */
+int gmx_batch_download(gmx_batch* b, uint64_t n_bits);  /* async D2H of p (and outputs) */
+int gmx_batch_wait(gmx_batch* b);                       /* host waits for the batch's queued work */
+/* Fill the DEVICE record buffers with the next n_bits of the synthetic stream of
+ * BASELINE.json configs[1] (xorshift64; logits on the [-4,4] grid, 32-bit contexts, random
+ * bits), generated on the GPU.  restart != 0 re-seeds stream s with
+ * seed + s * 0x9E3779B97F4A7C15; restart == 0 continues where this batch's previous fill
+ * stopped.  ctx_mode/ctx_mod/zero_mod/bit_mode as in oracle/gmx_synth.h. */
+int gmx_batch_fill_synthetic(gmx_batch* b, uint64_t n_bits, uint64_t seed, uint64_t restart,
+                             int ctx_mode, uint32_t ctx_mod, uint32_t zero_mod, int bit_mode);
+
+/* Predict (+ Perceive + Learn when learn != 0) for bits [0, n_bits) of every stream from the
+ * batch's device records; results land in the batch's device buffers.  Asynchronous on the
+ * group's stream; kernel_ms (nullable) receives the kernel's duration measured with HIP
+ * events on that stream, which makes the call synchronous. */
+int gmx_group_run(gmx_group* g, gmx_batch* b, uint64_t n_bits, int learn, float* kernel_ms);
+
+/* ---- persistence ------------------------------------------ */
+/* Byte-compatible with the reference: *short_bytes = Mixer::WriteToDisk of every mixer in
+ * order (3 x u64 each, mixer.cpp:178-182); *long_bytes = the mixer section of
+ * LongTermMemory::WriteToDisk (long-term-memory.cpp:35-55).  Call with NULL buffers to size. */
+int gmx_bank_export(gmx_group* g, int stream, void* long_buf, size_t* long_bytes,
+                    void* short_buf, size_t* short_bytes);
+int gmx_bank_import(gmx_group* g, int stream, const void* long_buf, size_t long_bytes,
+                    const void* short_buf, size_t short_bytes);
+/* Predictor::Copy for the mixer slice (mixer.cpp:190-195, long-term-memory.cpp:201-214). */
+int gmx_bank_copy(gmx_group* dst, int dst_stream, gmx_group* src, int src_stream);
+/* Mixer::GetMemoryUsage (mixer.cpp:197-205). */
+int gmx_bank_memory_usage(gmx_group* g, int stream, int mixer, uint64_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMXMIX_H_ */

@@ -1,0 +1,184 @@
+"""ctypes front-end of the CPU oracle (oracle/gmx_oracle.c) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+It also reads the GMXD dump files written by oracle/ref_build/ref_mixer_harness (the real
+reference), which is how the oracle itself is pinned (tests/test_oracle.py).
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    """Compile the C restatement (and, where /root/reference exists, oracle/_ref)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libgmxoracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.gmxo_create.restype = C.c_void_p
+        L.gmxo_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]
+        L.gmxo_destroy.argtypes = [C.c_void_p]
+        L.gmxo_predict.restype = C.c_float
+        L.gmxo_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.c_void_p]
+        L.gmxo_learn.argtypes = [C.c_void_p, C.c_int]
+        L.gmxo_run.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        for f in (L.gmxo_export_short, L.gmxo_export_long):
+            f.restype = C.c_size_t
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.gmxo_memory_usage.restype = C.c_uint64
+        L.gmxo_memory_usage.argtypes = [C.c_void_p, C.c_int]
+        L.gmxo_encode.restype = C.c_size_t
+        L.gmxo_encode.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.gmxo_synth_fill.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint32,
+                                      C.c_uint32, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]
+        L.gmxo_logistic.restype = C.c_float
+        L.gmxo_logistic.argtypes = [C.c_float]
+        L.gmxo_squash_clamp.restype = C.c_float
+        L.gmxo_squash_clamp.argtypes = [C.c_float]
+        L.gmxo_decay_base.restype = C.c_float
+        L.gmxo_decay_base.argtypes = [C.c_uint64]
+        L.gmxo_libm_expf_array.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.gmxo_discretize.restype = C.c_uint32
+        L.gmxo_discretize.argtypes = [C.c_float]
+        L.gmxo_fnv64.restype = C.c_uint64
+        L.gmxo_fnv64.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def synth(n, m, T, seed=0, ctx_mode=0, ctx_mod=1, zero_mod=0, bit_mode=0):
+    """Materialise the synthetic stream: (pred[T,n] raw, active[T,n] u8, ctx[T,m] u32, bits[T] u8)."""
+    pred = np.zeros((T, n), np.float32)
+    active = np.zeros((T, n), np.uint8)
+    ctx = np.zeros((T, m), np.uint32)
+    bits = np.zeros(T, np.uint8)
+    lib().gmxo_synth_fill(seed, n, m, ctx_mode, ctx_mod, zero_mod, bit_mode, T, _p(pred), _p(active),
+                          _p(ctx), _p(bits))
+    return pred, active, ctx, bits
+
+
+class Bank:
+    """One predictor's mixers, CPU restatement (dense tables)."""
+
+    def __init__(self, n, skip, topo):
+        """topo: list of (layer, table_size, lr) in construction order; skip: list of model indices."""
+        self.n, self.m = n, len(topo)
+        self.skip = np.asarray(list(skip), np.int32)
+        layer = np.asarray([t[0] for t in topo], np.int32)
+        table = np.asarray([t[1] for t in topo], np.uint32)
+        lr = np.asarray([t[2] for t in topo], np.float32)
+        self.h = lib().gmxo_create(n, len(self.skip), _p(self.skip), self.m, _p(layer), _p(table),
+                                   _p(lr))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().gmxo_destroy(self.h)
+            self.h = None
+
+    def predict(self, predictions, active_idx, ctx):
+        predictions = np.ascontiguousarray(predictions, np.float32)
+        active_idx = np.ascontiguousarray(active_idx, np.int32)
+        ctx = np.ascontiguousarray(ctx, np.uint32)
+        out = np.zeros(self.m, np.float32)
+        p = lib().gmxo_predict(self.h, _p(predictions), _p(active_idx), len(active_idx), _p(ctx),
+                               _p(out))
+        return p, out
+
+    def learn(self, bit):
+        lib().gmxo_learn(self.h, int(bit))
+
+    def run(self, pred, active, ctx, bits, nolearn_from=None, want_all=True):
+        T = len(bits)
+        pred = np.ascontiguousarray(pred, np.float32)
+        active = np.ascontiguousarray(active, np.uint8)
+        ctx = np.ascontiguousarray(ctx, np.uint32)
+        bits = np.ascontiguousarray(bits, np.uint8)
+        p = np.zeros(T, np.float32)
+        outs = np.zeros((T, self.m), np.float32) if want_all else None
+        nl = (1 << 64) - 1 if nolearn_from is None else nolearn_from
+        lib().gmxo_run(self.h, T, _p(pred), _p(active), _p(ctx), _p(bits), nl, _p(p), _p(outs))
+        return p, outs
+
+    def export_short(self):
+        n = lib().gmxo_export_short(self.h, None, 0)
+        buf = np.zeros(n, np.uint8)
+        lib().gmxo_export_short(self.h, _p(buf), n)
+        return buf.tobytes()
+
+    def export_long(self):
+        n = lib().gmxo_export_long(self.h, None, 0)
+        buf = np.zeros(max(n, 1), np.uint8)
+        lib().gmxo_export_long(self.h, _p(buf), n)
+        return buf.tobytes()[:n]
+
+    def memory_usage(self, j):
+        return lib().gmxo_memory_usage(self.h, j)
+
+
+def encode(bits, p):
+    """Arithmetic-code bits with probabilities p (coder/encoder.cpp restated); returns bytes."""
+    bits = np.ascontiguousarray(bits, np.uint8)
+    p = np.ascontiguousarray(p, np.float32)
+    n = lib().gmxo_encode(len(bits), _p(bits), _p(p), None, 0)
+    out = np.zeros(n, np.uint8)
+    lib().gmxo_encode(len(bits), _p(bits), _p(p), _p(out), n)
+    return out.tobytes()
+
+
+def fnv64(outs, p, h0=0):
+    """The harness's strong checksum: FNV-1a-style over out_all[t,:] then p[t], per bit."""
+    outs = np.ascontiguousarray(outs, np.float32)
+    p = np.ascontiguousarray(p, np.float32)
+    return lib().gmxo_fnv64(h0, len(p), outs.shape[1], _p(outs), _p(p))
+
+
+def read_dump(path):
+    """Parse a GMXD file from ref_mixer_harness into a dict."""
+    with open(path, "rb") as f:
+        b = f.read()
+    magic, ver, n, m, l0, l1, has_final, n_skip = struct.unpack_from("<8I", b, 0)
+    assert magic == 0x44584D47 and ver == 1
+    T, dump = struct.unpack_from("<2Q", b, 32)
+    off = 48
+    rec = np.frombuffer(b, np.float32, dump * (m + 1), off).reshape(dump, m + 1)
+    off += 4 * dump * (m + 1)
+    h32, = struct.unpack_from("<I", b, off)
+    off += 4
+    acc, = struct.unpack_from("<d", b, off)
+    off += 8
+    h64, = struct.unpack_from("<Q", b, off)
+    off += 8
+    ns, = struct.unpack_from("<Q", b, off)
+    off += 8
+    short = b[off:off + ns]
+    off += ns
+    nl, = struct.unpack_from("<Q", b, off)
+    off += 8
+    long_ = b[off:off + nl]
+    off += nl
+    mem = np.frombuffer(b, np.uint64, m, off).copy()
+    return dict(n=n, m=m, l0=l0, l1=l1, has_final=has_final, n_skip=n_skip, T=T, dump=dump,
+                outs=rec[:, :m].copy(), p=rec[:, m].copy(), h32=h32, acc=acc, h64=h64,
+                short=short, long=long_, mem=mem)
