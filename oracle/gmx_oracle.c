@@ -352,6 +352,43 @@ void gmxo_synth_fill(uint64_t seed, int n, int m, int ctx_mode, uint32_t ctx_mod
   free(c);
 }
 
+/* Stateful variant for long streams generated chunk by chunk. */
+typedef struct gmxo_stream {
+  gmx_synth g;
+  float* p;
+  uint8_t* a;
+  uint32_t* c;
+} gmxo_stream;
+
+gmxo_stream* gmxo_stream_new(uint64_t seed, int n, int m, int ctx_mode, uint32_t ctx_mod,
+                             uint32_t zero_mod, int bit_mode) {
+  gmxo_stream* s = (gmxo_stream*)calloc(1, sizeof(*s));
+  gmx_synth_init(&s->g, seed, n, m, ctx_mode, ctx_mod, zero_mod, bit_mode);
+  s->p = (float*)calloc(n ? n : 1, sizeof(float));
+  s->a = (uint8_t*)calloc(n ? n : 1, 1);
+  s->c = (uint32_t*)calloc(m ? m : 1, sizeof(uint32_t));
+  return s;
+}
+
+void gmxo_stream_next(gmxo_stream* s, uint64_t T, float* pred, uint8_t* active, uint32_t* ctx,
+                      uint8_t* bits) {
+  const int n = s->g.n, m = s->g.m;
+  for (uint64_t t = 0; t < T; ++t) {
+    bits[t] = (uint8_t)gmx_synth_step(&s->g, s->p, s->a, s->c);
+    memcpy(pred + t * n, s->p, sizeof(float) * n);
+    memcpy(active + t * n, s->a, n);
+    memcpy(ctx + t * m, s->c, sizeof(uint32_t) * m);
+  }
+}
+
+void gmxo_stream_free(gmxo_stream* s) {
+  if (!s) return;
+  free(s->p);
+  free(s->a);
+  free(s->c);
+  free(s);
+}
+
 /* libm probes used by tests/test_math.py to pin the product's own expf against the libm the
  * reference would link on this machine. */
 float gmxo_libm_expf(float x) { return expf(x); }

@@ -26,8 +26,9 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(_HERE, "libgmxoracle.so")
-        if not os.path.exists(path):
-            build()
+        src = [os.path.join(_HERE, f) for f in ("gmx_oracle.c", "gmx_synth.h")]
+        if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in src):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
         L = C.CDLL(path)
         L.gmxo_create.restype = C.c_void_p
         L.gmxo_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
@@ -58,6 +59,12 @@ def lib():
         L.gmxo_libm_expf_array.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.gmxo_discretize.restype = C.c_uint32
         L.gmxo_discretize.argtypes = [C.c_float]
+        L.gmxo_stream_new.restype = C.c_void_p
+        L.gmxo_stream_new.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                      C.c_int]
+        L.gmxo_stream_next.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]
+        L.gmxo_stream_free.argtypes = [C.c_void_p]
         L.gmxo_fnv64.restype = C.c_uint64
         L.gmxo_fnv64.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
         _LIB = L
@@ -77,6 +84,27 @@ def synth(n, m, T, seed=0, ctx_mode=0, ctx_mod=1, zero_mod=0, bit_mode=0):
     lib().gmxo_synth_fill(seed, n, m, ctx_mode, ctx_mod, zero_mod, bit_mode, T, _p(pred), _p(active),
                           _p(ctx), _p(bits))
     return pred, active, ctx, bits
+
+
+class Stream:
+    """The same synthetic stream, generated chunk by chunk (long runs)."""
+
+    def __init__(self, n, m, seed=0, ctx_mode=0, ctx_mod=1, zero_mod=0, bit_mode=0):
+        self.n, self.m = n, m
+        self.h = lib().gmxo_stream_new(seed, n, m, ctx_mode, ctx_mod, zero_mod, bit_mode)
+
+    def next(self, T):
+        pred = np.zeros((T, self.n), np.float32)
+        active = np.zeros((T, self.n), np.uint8)
+        ctx = np.zeros((T, self.m), np.uint32)
+        bits = np.zeros(T, np.uint8)
+        lib().gmxo_stream_next(self.h, T, _p(pred), _p(active), _p(ctx), _p(bits))
+        return pred, active, ctx, bits
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().gmxo_stream_free(self.h)
+            self.h = None
 
 
 class Bank:

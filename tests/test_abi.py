@@ -1,0 +1,70 @@
+"""The C-ABI library loads here (no GPU), exports every symbol include/gmxmix.h declares,
+validates topologies on the host, and refuses to compute without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import gmix_amd
+from gmix_amd import _lib, topology
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "gmxmix.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gmx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_exactly_the_header():
+    L = C.CDLL(gmix_amd.LIB_PATH)
+    declared = header_functions()
+    assert declared == sorted(gmix_amd.ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/gmxmix.h but not exported"
+
+
+def test_strerror_and_build_info():
+    L = _lib.lib()
+    assert L.gmx_strerror(0) == b"ok"
+    assert b"no CPU fallback" in L.gmx_strerror(-4)
+    assert b"gfx950" in L.gmx_build_info()
+
+
+def test_topology_bookkeeping_matches_reference_counts():
+    t = topology.stock(90)
+    ws = t.weight_sizes()
+    assert (t.l0, t.l1, t.has_final, t.n_mixers) == (24, 8, True, 33)
+    assert ws[:24] == list(range(90, 114)) and ws[24:32] == list(range(25, 33)) and ws[32] == 33
+    assert sum(ws) == 2697
+    assert sum(m[1] for m in t.mixers) == 343676  # total gate rows
+    assert t.bytes_per_bit() == 22072
+    assert topology.single(256).bytes_per_bit() == 3080
+    assert topology.synth3(256).bytes_per_bit() == 54608
+
+
+@pytest.mark.skipif(gmix_amd.device_count() > 0, reason="CPU-only behaviour")
+def test_no_device_means_no_compute():
+    with pytest.raises(gmix_amd.GmxError) as e:
+        gmix_amd.MixerGroup(topology.single(16, 8), 1)
+    assert e.value.status == -4  # GMX_ERR_NO_DEVICE: the product never falls back to the CPU
+
+
+def test_invalid_topologies_rejected():
+    bad = [
+        topology.Topology(16, [(1, 8, .1)], skip=()),                 # no layer-0 mixer
+        topology.Topology(16, [(0, 8, .1), (2, 1, .1), (2, 1, .1)]),  # two finals
+        topology.Topology(16, [(0, 8, .1), (1, 8, .1), (0, 8, .1)]),  # layers out of order
+        topology.Topology(16, [(0, 0, .1)]),                          # empty table
+        topology.Topology(16, [(0, 8, .1)] * 65),                     # too many mixers
+        topology.Topology(4096, [(0, 8, .1)]),                        # too many inputs
+        topology.Topology(16, [(0, 8, .1)], skip=(16,)),              # skip index out of range
+        topology.Topology(16, [(0, 8, .1)] * 64 + []),                # fine count but ...
+    ]
+    for t in bad[:-1]:
+        with pytest.raises(gmix_amd.GmxError) as e:
+            gmix_amd.MixerGroup(t, 1)
+        assert e.value.status == -1, t.mixers[:3]

@@ -1,0 +1,94 @@
+"""The oracle (oracle/gmx_oracle.c) against golden vectors recorded from the REFERENCE's own
+Mixer / Predictor in the build container (tests/golden/make_golden.py).  Integer compare of
+float bit patterns: tolerance 0."""
+import numpy as np
+import pytest
+
+import goldenlib
+from golden.cases import CASES
+
+SHORT = [n for n, c in CASES.items() if c[1] <= 10000]
+LONG = [n for n, c in CASES.items() if c[1] > 10000]
+
+
+def replay(oracle, meta, chunk=50000):
+    topo = goldenlib.topo_of(meta)
+    kw, nolearn = goldenlib.synth_kwargs(meta)
+    T = meta["T"]
+    st = oracle.Stream(topo.n_inputs, topo.n_mixers, **kw)
+    bank = oracle.Bank(topo.n_inputs, topo.skip, topo.mixers)
+    h = 0
+    outs_all, p_all = [], []
+    for t0 in range(0, T, chunk):
+        n = min(chunk, T - t0)
+        pred, act, ctx, bits = st.next(n)
+        nl = None if nolearn is None else max(0, nolearn - t0)
+        p, outs = bank.run(pred, act, ctx, bits, nolearn_from=nl)
+        h = oracle.fnv64(outs, p, h0=h)
+        if t0 < meta["dump"]:
+            outs_all.append(outs)
+            p_all.append(p)
+    return bank, h, (np.concatenate(outs_all) if outs_all else None), (np.concatenate(p_all) if p_all else None)
+
+
+def check(oracle, name):
+    meta, z = goldenlib.load(name)
+    bank, h, outs, p = replay(oracle, meta)
+    assert h == meta["h64"], f"{name}: running checksum over all {meta['T']} bits differs"
+    d = meta["dump"]
+    if d:
+        assert np.array_equal(outs[:d].view(np.uint32), z["outs"])
+        assert np.array_equal(p[:d].view(np.uint32), z["p"])
+    assert bank.export_short().hex() == meta["short_hex"]
+    lb = bank.export_long()
+    assert len(lb) == meta["long_len"] and goldenlib.sha256(lb) == meta["long_sha256"]
+    if len(z["long"]):
+        assert lb == z["long"].tobytes()
+    assert [bank.memory_usage(j) for j in range(len(meta["mixers"]))] == list(z["mem"])
+
+
+@pytest.mark.parametrize("name", SHORT)
+def test_oracle_matches_reference_short(oracle, name):
+    check(oracle, name)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name", LONG)
+def test_oracle_matches_reference_long(oracle, name):
+    """SURVEY.md Appendix A.3 runs (the 24/8/1 ones reproduce the survey's own hashes
+    b864caa7 / f003db20)."""
+    check(oracle, name)
+    meta, _ = goldenlib.load(name)
+    if name == "a3_synth3_n256":
+        assert meta["h32"] == 0xb864caa7 and abs(meta["acc"] - 18.811666) < 1e-6
+    if name == "a3_synth3_n90":
+        assert meta["h32"] == 0xf003db20 and abs(meta["acc"] + 20.275474) < 1e-6
+
+
+def test_oracle_matches_reference_predictor_trace(oracle):
+    """Real feature-model inputs: the whole reference Predictor on english.dic, recorded at
+    the mixer boundary.  Stale slots, ~40% silent models, real contexts."""
+    meta, z = goldenlib.load("trace_english")
+    pred, act, ctx, bits, outs_ref, p_ref = goldenlib.unpack_trace(z, meta)
+    topo = goldenlib.topo_of(meta)
+    assert topo.weight_sizes() == meta["weight_sizes"]
+    bank = oracle.Bank(topo.n_inputs, topo.skip, topo.mixers)
+    p, outs = bank.run(pred, act, ctx, bits)
+    assert np.array_equal(outs.view(np.uint32), outs_ref)
+    assert np.array_equal(p.view(np.uint32), p_ref)
+    assert bank.export_short().hex() == meta["short_hex"]
+    lb = bank.export_long()
+    assert len(lb) == meta["long_len"] and goldenlib.sha256(lb) == meta["long_sha256"]
+
+
+def test_coder_restatement(oracle):
+    """Encoder (coder/encoder.cpp) restated: sanity properties -- deterministic, 16-bit
+    probabilities, a skewed stream shrinks, a uniform one does not."""
+    rng = np.random.default_rng(1)
+    bits = (rng.random(20000) < 0.1).astype(np.uint8)
+    p = np.full(20000, 0.1, np.float32)
+    a = oracle.encode(bits, p)
+    assert a == oracle.encode(bits, p) and len(a) < 20000 / 8 * 0.55
+    u = oracle.encode(bits, np.full(20000, 0.5, np.float32))
+    assert abs(len(u) - 2500) <= 3
+    assert oracle.lib().gmxo_discretize(np.float32(0.5)) == 32768
