@@ -70,10 +70,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=2048, help="independent streams per GPU")
+    ap.add_argument("--streams", type=int, default=3072,
+                    help="independent streams per GPU (each owns a dense 64.5 MiB gate table: 3072 = 194 GiB of HBM)")
     ap.add_argument("--bits", type=int, default=512, help="bits per stream per step")
     ap.add_argument("--config", default="single")
     ap.add_argument("--ring", type=int, default=4, help="distinct record batches cycled through")
+    ap.add_argument("--variant", type=int, default=0,
+                    help="tuning: lanes per stream of the single-mixer kernel (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-bits", type=int, default=4_000_000)
     args = ap.parse_args()
@@ -106,7 +109,11 @@ def main():
         except gmix_amd.GmxError as e:
             if e.status != -2 or S <= 64:
                 raise
-            S //= 2  # dense tables did not fit: halve the stream count
+            S = max(64, (S * 3 // 4) // 64 * 64)  # dense tables did not fit: fewer streams
+    if args.variant:
+        import ctypes
+        g.L.gmx_debug_single_variant.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        assert g.L.gmx_debug_single_variant(g.h, args.variant) == 0
     ring = [gmix_amd.Batch(g, T, outputs=False, mask=False) for _ in range(args.ring)]
     for i, b in enumerate(ring):
         b.fill_synthetic(T, seed=0x9E3779B97F4A7C15 + 1000003 * (rank * args.ring + i), restart=True)
@@ -153,7 +160,8 @@ def main():
                        "bank_bytes_per_stream": g.bank_bytes, "parallelism": f"streams sharded over {n_gpus} GPU(s), no collective on the data path"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "gmx_bank_kernel", "kernel_ms_avg": avg_ms,
+                         "kernel": "gmx_single_kernel" if topo.n_mixers == 1 else "gmx_bank_kernel",
+                         "kernel_ms_avg": avg_ms,
                          "algorithmic_bytes_per_bit": topo.bytes_per_bit(),
                          "bytes_per_launch": bytes_per_launch},
         }

@@ -37,6 +37,8 @@ extern "C" {
 hipError_t gmx_launch_bank_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_streams,
                                   unsigned lds_bytes, int has_mask, hipStream_t stream);
 hipError_t gmx_bank_kernel_set_lds(unsigned lds_bytes);
+hipError_t gmx_launch_single_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_inputs,
+                                    int variant, hipStream_t stream);
 hipError_t gmx_launch_synth_kernel(const GmxSynthArgs* args, hipStream_t stream);
 hipError_t gmx_launch_init_scal(uint8_t* banks, uint64_t bank_bytes, uint64_t scal_off, int m,
                                 int n_streams, hipStream_t stream);
@@ -80,6 +82,8 @@ struct gmx_group {
   size_t decay_cap = 0;            // floats
   gmx_batch* one = nullptr;        // 1-bit batch (one record per stream) of the per-bit surface
   std::vector<gmx_batch*> batches; // live batches; orphaned (b->g = nullptr) when the group dies
+  bool force_general = false;      // tests: route everything through the general kernel
+  int single_variant = 0;          // tests/tuning: lanes per stream of the single-mixer kernel (0 = default)
 };
 
 struct gmx_batch {
@@ -399,8 +403,16 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
   a.mode = mode;
   a.stream_base = s0;
   a.rec_base = rec0;
+  a.n_streams = ns;
   if (kernel_ms) HIPCHK(hipEventRecord(g->ev0, g->stream));
-  HIPCHK(gmx_launch_bank_kernel(g->topo_dev, &a, ns, g->lds_bytes, a.mask != nullptr, g->stream));
+  // Banks that are a single layer-0 mixer take the register-resident throughput kernel
+  // (gmx_single.hip); everything else, and every per-bit call, the general kernel.
+  const bool single = g->topo.m == 1 && g->topo.n <= 256 && !a.mask && (mode & GMX_MODE_PREDICT) &&
+                      !(mode & GMX_MODE_LATCH) && !g->force_general;
+  if (single)
+    HIPCHK(gmx_launch_single_kernel(g->topo_dev, &a, g->topo.n, g->single_variant, g->stream));
+  else
+    HIPCHK(gmx_launch_bank_kernel(g->topo_dev, &a, ns, g->lds_bytes, a.mask != nullptr, g->stream));
   if (kernel_ms) {
     HIPCHK(hipEventRecord(g->ev1, g->stream));
     HIPCHK(hipEventSynchronize(g->ev1));
@@ -812,6 +824,20 @@ extern "C" int gmx_bank_memory_usage(gmx_group* g, int stream, int mixer, uint64
 }
 
 // ---- test probes (device math against host math; not part of the product surface) --------
+extern "C" int gmx_debug_single_variant(gmx_group* g, int lanes_per_stream) {
+  if (!g || (lanes_per_stream != 0 && lanes_per_stream != 16 && lanes_per_stream != 32 &&
+             lanes_per_stream != 64))
+    return GMX_ERR_INVALID;
+  g->single_variant = lanes_per_stream;
+  return GMX_OK;
+}
+
+extern "C" int gmx_debug_force_general(gmx_group* g, int on) {
+  if (!g) return GMX_ERR_INVALID;
+  g->force_general = on != 0;
+  return GMX_OK;
+}
+
 extern "C" int gmx_debug_math_probe(int device, const float* x, float* y, uint64_t n, int what) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {

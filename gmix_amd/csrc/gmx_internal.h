@@ -57,6 +57,7 @@ struct GmxRunArgs {
   uint32_t mode;
   int32_t stream_base;        // bank of block 0
   int32_t rec_base;           // record-array stream index of block 0
+  int32_t n_streams;          // streams this launch covers
 };
 
 #endif  // GMX_INTERNAL_H_

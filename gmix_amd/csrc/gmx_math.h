@@ -15,6 +15,12 @@
 // float inputs on the host, and tests/test_gpu_math.py compares device with host over the
 // same set, so "same float as the reference's Logistic" is a tested fact, not a hope.
 //
+// The special cases (|x| >= 88, infinities, NaN) are applied as selects after the main
+// path instead of branches before it: same results, and no divergent branch in the middle
+// of a kernel's basic block.  The 2^(i/32) table can be supplied by the caller so that the
+// kernels read it from LDS (a lookup in global memory would sit in the same in-order
+// vmcnt queue as the prefetched weight rows and drain it on every bit).
+//
 // Nothing here may be contracted or re-associated by the compiler: build with
 // -ffp-contract=off (Makefile) -- the fused operations are spelled out as gmx_fma().
 #ifndef GMX_MATH_H_
@@ -69,8 +75,9 @@ GMX_HD double gmx_u2d(uint64_t u) {
   return d;
 }
 
-// expf as glibc 2.27+ computes it on FMA-capable x86-64 (see file header).
-GMX_HD float gmx_expf(float x) {
+// expf as glibc 2.27+ computes it on FMA-capable x86-64 (see file header); `tab` is
+// gmx_exp2f_tab or a copy of it.
+GMX_HD float gmx_expf_tab(float x, const uint64_t* tab) {
   const double kShift = 0x1.8p+52;
   const double kInvLn2N = 0x1.71547652b82fep+0 * 32;
   const double kC0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32;
@@ -78,40 +85,43 @@ GMX_HD float gmx_expf(float x) {
   const double kC2 = 0x1.62e42ff0c52d6p-1 / 32;
   const uint32_t ux = gmx_f2u(x);
   const uint32_t abstop = (ux >> 20) & 0x7ff;
-  if (abstop >= 0x42b) {              // |x| >= 88 or NaN
-    if (ux == 0xff800000u) return 0.0f;        // exp(-inf)
-    if (abstop >= 0x7f8) return x + x;         // +inf, NaN
-    if (x > 0x1.62e42ep6f) return gmx_u2f(0x7f800000u);   // overflow
-    if (x < -0x1.9fe368p6f) return 0.0f;                  // underflow
-    if (x < -0x1.9d1d9ep6f) return gmx_u2f(1u);           // 0x1.4p-75f * 0x1.4p-75f -> 2^-149
-  }
+  // main path (meaningful for |x| < ~104; harmless garbage beyond, overridden below)
   const double xd = (double)x;
-  double kd = gmx_fma(kInvLn2N, xd, kShift);   // round(x*N/ln2) in the low mantissa bits
+  double kd = gmx_fma(kInvLn2N, xd, kShift);    // round(x*N/ln2) in the low mantissa bits
   const uint64_t ki = gmx_d2u(kd);
   kd -= kShift;
-  const double r = gmx_fma(kInvLn2N, xd, -kd); // x*N/ln2 - k, one rounding
-  const uint64_t t = gmx_exp2f_tab[ki & 31] + (ki << 47);
+  const double r = gmx_fma(kInvLn2N, xd, -kd);  // x*N/ln2 - k, one rounding
+  const uint64_t t = tab[ki & 31] + (ki << 47);
   const double s = gmx_u2d(t);
   const double z = gmx_fma(kC0, r, kC1);
   const double r2 = r * r;
   double y = gmx_fma(kC2, r, 1.0);
   y = gmx_fma(z, r2, y);
   y = y * s;
-  return (float)y;
+  float res = (float)y;
+  // special cases of e_expf.c, in its order of precedence (last assignment wins here)
+  const bool big = abstop >= 0x42b;                               // |x| >= 88 or NaN
+  res = (big && x < -0x1.9d1d9ep6f) ? gmx_u2f(1u) : res;          // 0x1.4p-75f squared = 2^-149
+  res = (big && x < -0x1.9fe368p6f) ? 0.0f : res;                 // underflow
+  res = (big && x > 0x1.62e42ep6f) ? gmx_u2f(0x7f800000u) : res;  // overflow
+  res = (abstop >= 0x7f8) ? x + x : res;                          // +-inf, NaN
+  res = (ux == 0xff800000u) ? 0.0f : res;                         // exp(-inf)
+  return res;
 }
+
+GMX_HD float gmx_expf(float x) { return gmx_expf_tab(x, gmx_exp2f_tab); }
 
 // Sigmoid::Logistic (mixer/sigmoid.cpp:5): float add and IEEE float divide.
-GMX_HD float gmx_logistic(float p) { return 1.0f / (1.0f + gmx_expf(-p)); }
+GMX_HD float gmx_logistic_tab(float p, const uint64_t* tab) {
+  return 1.0f / (1.0f + gmx_expf_tab(-p, tab));
+}
+GMX_HD float gmx_logistic(float p) { return gmx_logistic_tab(p, gmx_exp2f_tab); }
 
 // Final squash of Predictor::Predict (predictor.cpp:369-375): clamp to [1e-4f, 1-1e-4f].
-GMX_HD float gmx_squash_clamp(float out) {
-  float prob = gmx_logistic(out);
+GMX_HD float gmx_clamp_prob(float prob) {
   const float eps = 0.0001f;
-  if (prob < eps)
-    prob = eps;
-  else if (prob > 1.0f - eps)
-    prob = 1.0f - eps;
-  return prob;
+  return prob < eps ? eps : (prob > 1.0f - eps ? 1.0f - eps : prob);
 }
+GMX_HD float gmx_squash_clamp(float out) { return gmx_clamp_prob(gmx_logistic(out)); }
 
 #endif  // GMX_MATH_H_
