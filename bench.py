@@ -85,7 +85,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("GMX_BENCH_FORCE_DIST"):  # the env var rehearses the N>1 path on one GPU
         # torch first: libgmxmix.so then binds to the HIP runtime torch has already loaded
         # (same soname), so RCCL and the mixer kernels share one runtime in this process.
         import torch
@@ -137,10 +137,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        import torch
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+        from gmix_amd import shard
+        elapsed = shard.max_over_ranks(elapsed, dist, device="cuda")
 
     if rank == 0:
         bits_per_step = S * T * n_gpus
@@ -165,6 +163,20 @@ def main():
                          "algorithmic_bytes_per_bit": topo.bytes_per_bit(),
                          "bytes_per_launch": bytes_per_launch},
         }
+        # HBM traffic per launch comes from rocprofv3 PMC passes of this same command (they
+        # cannot run inside the timed process); the committed summary is quoted when it was
+        # taken on the same launch shape, otherwise the field stays null.
+        try:
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+                pm = json.load(open(f))
+                if (pm.get("streams"), pm.get("bits_per_stream")) == (S, T) and \
+                        pm.get("kernel", "").startswith(out["roofline"]["kernel"]):
+                    out["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = os.path.relpath(f, ROOT)
+                    break
+        except Exception as e:
+            sys.stderr.write(f"[bench] no PMC summary: {e}\n")
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(topo, args.cpu_sample_bits)
         print(json.dumps(out), flush=True)

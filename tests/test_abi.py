@@ -68,3 +68,16 @@ def test_invalid_topologies_rejected():
         with pytest.raises(gmix_amd.GmxError) as e:
             gmix_amd.MixerGroup(t, 1)
         assert e.value.status == -1, t.mixers[:3]
+
+
+def test_cpp_host_mirror_compiles_and_links(tmp_path):
+    """gmix_amd/host/gmx_mixer.h (the C++ mirror of Mixer / Predictor) builds with plain g++
+    against the C ABI; running it needs a GPU (tests/test_gpu_host_cpp.py)."""
+    import subprocess
+    exe = str(tmp_path / "t")
+    subprocess.check_call([
+        "g++", "-std=c++17", "-Wall", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_host_adapter.cpp"),
+        "-L" + os.path.join(ROOT, "gmix_amd"), "-lgmxmix", "-L" + os.path.join(ROOT, "oracle"), "-lgmxoracle",
+        "-Wl,-rpath," + os.path.join(ROOT, "gmix_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+        "-Wl,-rpath,/opt/rocm/lib"])
+    assert os.path.exists(exe)
