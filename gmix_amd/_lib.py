@@ -5,7 +5,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgmxmix.so")
+# GMX_LIB overrides the library file (an instrumented build of the same sources, for profiling)
+LIB_PATH = os.environ.get("GMX_LIB") or os.path.join(_HERE, "libgmxmix.so")
 _LIB = None
 
 

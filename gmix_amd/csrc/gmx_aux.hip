@@ -1,0 +1,167 @@
+// gmx_aux.hip -- small gfx950 kernels around the hot path: the synthetic record generator
+// of the benchmark, the device-side math probes of the parity tests, bank initialisation.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gmx_internal.h"
+#include "gmx_math.h"
+
+// ---------------------------------------------------------------------------------------
+// Synthetic record generator (BASELINE.json configs[1]; definition in oracle/gmx_synth.h,
+// restated here for the device): one thread walks one stream's xorshift64 sequence.
+// ---------------------------------------------------------------------------------------
+struct GmxSynthArgs {
+  float* pred;        // [S][rec_stride][n_pad]
+  uint32_t* mask;     // [S][rec_stride][mask_words] or null
+  uint32_t* ctx;      // [S][rec_stride][m]
+  uint8_t* bits;      // [S][rec_stride]
+  uint64_t* rng;      // [S] persistent xorshift state
+  uint64_t* tcount;   // [S] bits generated so far (for the every-8th-bit context modes)
+  float* pstate;      // [S][n_pad] persistent prediction slots
+  uint32_t* cstate;   // [S][m] persistent contexts
+  uint64_t rec_stride, n_bits, seed;
+  int32_t n, n_pad, m, mask_words, n_streams, restart, ctx_mode, bit_mode;
+  uint32_t ctx_mod, zero_mod;
+};
+
+__device__ __forceinline__ uint32_t gmx_xs64(uint64_t& s) {
+  s ^= s << 13;
+  s ^= s >> 7;
+  s ^= s << 17;
+  return (uint32_t)(s >> 11);
+}
+
+__global__ void __launch_bounds__(64) gmx_synth_kernel(const GmxSynthArgs a) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.n_streams) return;
+  float* pst = a.pstate + (uint64_t)s * a.n_pad;
+  uint32_t* cst = a.cstate + (uint64_t)s * a.m;
+  uint64_t st, tc;
+  if (a.restart) {
+    st = a.seed + (uint64_t)s * 0x9E3779B97F4A7C15ull;
+    if (st == 0) st = 0x9E3779B97F4A7C15ull;
+    tc = 0;
+    for (int i = 0; i < a.n_pad; ++i) pst[i] = 0.f;
+    for (int j = 0; j < a.m; ++j) cst[j] = 0u;
+  } else {
+    st = a.rng[s];
+    tc = a.tcount[s];
+  }
+  const uint32_t cmod = a.ctx_mod ? a.ctx_mod : 1u;
+  for (uint64_t t = 0; t < a.n_bits; ++t) {
+    float* pr = a.pred + ((uint64_t)s * a.rec_stride + t) * a.n_pad;
+    uint32_t* mk = a.mask ? a.mask + ((uint64_t)s * a.rec_stride + t) * a.mask_words : nullptr;
+    uint32_t* cx = a.ctx + ((uint64_t)s * a.rec_stride + t) * a.m;
+    uint32_t mword = 0;
+    for (int i = 0; i < a.n; ++i) {
+      bool act = false;
+      bool silent = false;
+      if (a.zero_mod) {
+        const uint32_t dr = gmx_xs64(st);
+        silent = (dr % a.zero_mod) == 0;
+      }
+      if (!silent) {
+        const float x = (float)((int)(gmx_xs64(st) % 2001u) - 1000) / 250.0f;
+        pst[i] = x;
+        act = (x != 0.0f);
+      }
+      pr[i] = pst[i];
+      if (act) mword |= 1u << (i & 31);
+      if ((i & 31) == 31 || i == a.n - 1) {
+        if (mk) mk[i >> 5] = mword;
+        mword = 0;
+      }
+    }
+    for (int i = a.n; i < a.n_pad; ++i) pr[i] = 0.f;
+    const bool redraw = (a.ctx_mode < 2) || ((tc & 7u) == 0);
+    if (redraw) {
+      for (int j = 0; j < a.m; ++j) {
+        uint32_t c = gmx_xs64(st);
+        if (a.ctx_mode & 1) c %= cmod;
+        cst[j] = c;
+      }
+    }
+    for (int j = 0; j < a.m; ++j) cx[j] = cst[j];
+    ++tc;
+    const uint32_t r = gmx_xs64(st);
+    uint32_t bit = r & 1u;
+    if (a.bit_mode == 1) bit = (uint32_t)((pst[0] > 0.0f) ^ ((r & 7u) == 0));
+    a.bits[(uint64_t)s * a.rec_stride + t] = (uint8_t)bit;
+  }
+  a.rng[s] = st;
+  a.tcount[s] = tc;
+}
+
+extern "C" hipError_t gmx_launch_synth_kernel(const GmxSynthArgs* args, hipStream_t stream) {
+  const int blocks = (args->n_streams + 63) / 64;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gmx_synth_kernel, dim3(blocks), dim3(64), 0, stream, *args);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Device-side math probes for the parity tests (the same gmx_math.h the kernels use).
+// ---------------------------------------------------------------------------------------
+__global__ void gmx_math_probe_kernel(const float* x, float* y, uint64_t n, int what) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  y[i] = what == 0 ? gmx_expf(v) : (what == 1 ? gmx_logistic(v) : gmx_squash_clamp(v));
+}
+
+// Compare device gmx_expf / gmx_logistic over a whole range of float bit patterns against a
+// host-computed table is too slow over PCIe; instead the device checksums its results and
+// the host checksums its own: out[0] = xor-fold, out[1] = sum of the result bit patterns.
+__global__ void gmx_math_range_kernel(uint64_t lo, uint64_t count, int what,
+                                      unsigned long long* out) {
+  unsigned long long x = 0, sacc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t u = (uint32_t)(lo + i);
+    const float v = gmx_u2f(u);
+    float r = what == 0 ? gmx_expf(v) : (what == 1 ? gmx_logistic(v) : gmx_squash_clamp(v));
+    uint32_t rb = gmx_f2u(r);
+    if (r != r) rb = 0x7fc00000u;  // all NaNs alike
+    x ^= (unsigned long long)rb * 0x9E3779B97F4A7C15ull + u;
+    sacc += rb;
+  }
+  atomicXor(&out[0], x);
+  atomicAdd(&out[1], sacc);
+}
+
+extern "C" hipError_t gmx_launch_math_probe(const float* x, float* y, uint64_t n, int what,
+                                            hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gmx_math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                     x, y, n, what);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t gmx_launch_math_range(uint64_t lo, uint64_t count, int what,
+                                            unsigned long long* out, hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gmx_math_range_kernel, dim3(2048), dim3(256), 0, stream, lo, count, what, out);
+  return hipGetLastError();
+}
+
+// Constructed state of every Mixer: steps_ = 0, max_steps_ = 1, contexts_seen_ = 0
+// (mixer.cpp:8-9, mixer.h:38); the tables themselves are zero-filled by the host side.
+__global__ void gmx_init_scal_kernel(uint8_t* banks, uint64_t bank_bytes, uint64_t scal_off, int m,
+                                     int n_streams) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m * n_streams) return;
+  const int s = i / m, j = i % m;
+  uint64_t* sc = (uint64_t*)(banks + (uint64_t)s * bank_bytes + scal_off) + 3 * j;
+  sc[0] = 0;
+  sc[1] = 1;
+  sc[2] = 0;
+}
+
+extern "C" hipError_t gmx_launch_init_scal(uint8_t* banks, uint64_t bank_bytes, uint64_t scal_off,
+                                           int m, int n_streams, hipStream_t stream) {
+  const int n = m * n_streams;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gmx_init_scal_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, banks,
+                     bank_bytes, scal_off, m, n_streams);
+  return hipGetLastError();
+}

@@ -35,7 +35,8 @@ struct GmxSynthArgs {
 
 extern "C" {
 hipError_t gmx_launch_bank_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_streams,
-                                  unsigned lds_bytes, int has_mask, hipStream_t stream);
+                                  unsigned lds_bytes, int has_mask, int l0, int l1, int ns, int fin,
+                                  unsigned stride0, hipStream_t stream);
 hipError_t gmx_bank_kernel_set_lds(unsigned lds_bytes);
 hipError_t gmx_launch_single_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_inputs,
                                     int variant, hipStream_t stream);
@@ -192,6 +193,11 @@ static int build_topology(const gmx_topology* t, GmxTopoDev* o) {
   if (o->l0 < 1) return GMX_ERR_INVALID;
   for (int j = o->l0; j < o->m; ++j)
     if (o->mx[j].weight_size > 64) return GMX_ERR_INVALID;  // layer-1/final rows: one lane per weight
+  // Stored row lengths are uniform per layer group, so the update passes run without
+  // per-row lane masks: every layer-0 row as long as the longest one (the cascade makes
+  // them differ by at most l0-1 weights), every layer-1/final row 64 floats (one per lane).
+  for (int j = 0; j < o->l0; ++j) o->mx[j].stride = o->mx[o->l0 - 1].stride;
+  for (int j = o->l0; j < o->m; ++j) o->mx[j].stride = 64;
   // bank layout in HBM: weight tables, then row-step tables, then per-mixer scalars
   uint64_t off = 0;
   for (int j = 0; j < o->m; ++j) {
@@ -217,9 +223,22 @@ static int build_topology(const gmx_topology* t, GmxTopoDev* o) {
   l += GMX_MAX_SKIP;
   o->lds_misc = l;
   l += 256;
-  for (int j = 0; j < o->m; ++j) {
-    o->mx[j].lds_off = l;
-    l += 2 * o->mx[j].pitch;
+  // Row cache: per layer group (layer 0 | layers 1+2) all slot-0 rows, then all slot-1 rows,
+  // every row of a group D = longest stride + 4 floats apart.  D/4 is odd and the slot-1
+  // image starts a multiple of 64 floats later, so the 16 lanes of a ds_read_b128 group that
+  // read "their mixer's current row at element j" always hit 16 different bank quads.
+  for (int grp = 0; grp < 2; ++grp) {
+    const int lo = grp == 0 ? 0 : o->l0, hi = grp == 0 ? o->l0 : o->m;
+    if (lo >= hi) continue;
+    uint32_t dmax = 0;
+    for (int j = lo; j < hi; ++j) dmax = std::max(dmax, o->mx[j].stride);
+    const uint32_t D = dmax + 4;
+    const uint32_t S = round_up((uint32_t)(hi - lo) * D, 64);
+    for (int j = lo; j < hi; ++j) {
+      o->mx[j].lds_off = l + (uint32_t)(j - lo) * D;
+      o->mx[j].pitch = S;  // distance from a mixer's slot 0 to its slot 1
+    }
+    l += 2 * S;
   }
   o->lds_total = l;
   if ((uint64_t)o->lds_total * 4u > 160u * 1024u) return GMX_ERR_INVALID;
@@ -412,7 +431,9 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
   if (single)
     HIPCHK(gmx_launch_single_kernel(g->topo_dev, &a, g->topo.n, g->single_variant, g->stream));
   else
-    HIPCHK(gmx_launch_bank_kernel(g->topo_dev, &a, ns, g->lds_bytes, a.mask != nullptr, g->stream));
+    HIPCHK(gmx_launch_bank_kernel(g->topo_dev, &a, ns, g->lds_bytes, a.mask != nullptr, g->topo.l0,
+                                  g->topo.l1, g->topo.n_skip, g->topo.has_final,
+                                  g->topo.mx[g->topo.l0 - 1].stride, g->stream));
   if (kernel_ms) {
     HIPCHK(hipEventRecord(g->ev1, g->stream));
     HIPCHK(hipEventSynchronize(g->ev1));

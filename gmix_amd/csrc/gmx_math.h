@@ -28,6 +28,9 @@
 
 #include <stdint.h>
 #include <string.h>
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
