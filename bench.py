@@ -77,6 +77,10 @@ def main():
     ap.add_argument("--ring", type=int, default=4, help="distinct record batches cycled through")
     ap.add_argument("--variant", type=int, default=0,
                     help="tuning: lanes per stream of the single-mixer kernel (0 = library default)")
+    ap.add_argument("--ctx-mode", type=int, default=0,
+                    help="0: fresh 32-bit gate contexts every bit (BASELINE configs[1]); 2/3: contexts held "
+                         "for 8 bits like byte-boundary contexts (oracle/gmx_synth.h)")
+    ap.add_argument("--ctx-mod", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-bits", type=int, default=4_000_000)
     args = ap.parse_args()
@@ -116,7 +120,8 @@ def main():
         assert g.L.gmx_debug_single_variant(g.h, args.variant) == 0
     ring = [gmix_amd.Batch(g, T, outputs=False, mask=False) for _ in range(args.ring)]
     for i, b in enumerate(ring):
-        b.fill_synthetic(T, seed=0x9E3779B97F4A7C15 + 1000003 * (rank * args.ring + i), restart=True)
+        b.fill_synthetic(T, seed=0x9E3779B97F4A7C15 + 1000003 * (rank * args.ring + i), restart=True,
+                         ctx_mode=args.ctx_mode, ctx_mod=args.ctx_mod)
     g.sync()
 
     for k in range(args.warmup):

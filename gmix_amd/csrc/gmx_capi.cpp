@@ -38,6 +38,8 @@ hipError_t gmx_launch_bank_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* ar
                                   unsigned lds_bytes, int has_mask, int l0, int l1, int ns, int fin,
                                   unsigned stride0, hipStream_t stream);
 hipError_t gmx_bank_kernel_set_lds(unsigned lds_bytes);
+hipError_t gmx_launch_stock_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_streams,
+                                   unsigned lds_bytes, int has_mask, hipStream_t stream);
 hipError_t gmx_launch_single_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_inputs,
                                     int variant, hipStream_t stream);
 hipError_t gmx_launch_synth_kernel(const GmxSynthArgs* args, hipStream_t stream);
@@ -428,8 +430,15 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
   // (gmx_single.hip); everything else, and every per-bit call, the general kernel.
   const bool single = g->topo.m == 1 && g->topo.n <= 256 && !a.mask && (mode & GMX_MODE_PREDICT) &&
                       !(mode & GMX_MODE_LATCH) && !g->force_general;
+  // The reference's own shape (90 inputs, 24/8/1, one skip input) runs with its rows in
+  // registers (gmx_stock.hip); it only needs the small part of the LDS image.
+  const bool stock = g->topo.n == 90 && g->topo.l0 == 24 && g->topo.l1 == 8 && g->topo.n_skip == 1 &&
+                     g->topo.has_final && g->topo.mx[23].stride == 128 && !g->force_general;
   if (single)
     HIPCHK(gmx_launch_single_kernel(g->topo_dev, &a, g->topo.n, g->single_variant, g->stream));
+  else if (stock)
+    HIPCHK(gmx_launch_stock_kernel(g->topo_dev, &a, ns, (g->topo.lds_misc + 256u) * 4u,
+                                   a.mask != nullptr, g->stream));
   else
     HIPCHK(gmx_launch_bank_kernel(g->topo_dev, &a, ns, g->lds_bytes, a.mask != nullptr, g->topo.l0,
                                   g->topo.l1, g->topo.n_skip, g->topo.has_final,

@@ -81,3 +81,21 @@ def test_cpp_host_mirror_compiles_and_links(tmp_path):
         "-Wl,-rpath," + os.path.join(ROOT, "gmix_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
         "-Wl,-rpath,/opt/rocm/lib"])
     assert os.path.exists(exe)
+
+
+def test_kernels_do_not_spill_to_scratch():
+    """The bit-loop kernels issue their vector-memory instructions by hand and wait with counted
+    s_waitcnt vmcnt(N): a compiler-inserted scratch spill (a VMEM instruction the count does
+    not know about) would silently break that bookkeeping.  Assert the resource report."""
+    import subprocess
+    src = os.path.join(ROOT, "gmix_amd", "csrc")
+    for f in ("gmx_single.hip", "gmx_stock.hip", "gmx_kernels.hip"):
+        out = subprocess.run(
+            ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+             "-fno-gpu-flush-denormals-to-zero", "-c", os.path.join(src, f), "-o", "/dev/null",
+             "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd=src)
+        report = out.stderr + out.stdout
+        scratch = re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", report)
+        vspill = re.findall(r"VGPRs Spill: (\d+)", report)
+        assert scratch and all(s == "0" for s in scratch), (f, scratch)
+        assert all(s == "0" for s in vspill), (f, vspill)

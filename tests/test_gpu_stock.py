@@ -1,0 +1,75 @@
+"""The register-resident kernel for the reference's own shape (gmx_stock.hip: 90 inputs,
+24/8/1, one skip input) against the general kernel and the oracle -- same floats, same state."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gmix_amd import topology
+
+pytestmark = pytest.mark.gpu
+
+
+def beq(a, b):
+    return np.array_equal(np.ascontiguousarray(a, np.float32).view(np.uint32),
+                          np.ascontiguousarray(b, np.float32).view(np.uint32))
+
+
+def run(gpu, topo, streams, chunk, force_general, mask=True, learn=True):
+    S, T = len(streams), len(streams[0][3])
+    g = gpu.MixerGroup(topo, S)
+    g.L.gmx_debug_force_general.argtypes = [C.c_void_p, C.c_int]
+    g.L.gmx_debug_force_general(g.h, 1 if force_general else 0)
+    b = gpu.Batch(g, chunk, outputs=True, mask=mask)
+    P = np.zeros((S, T), np.float32)
+    O = np.zeros((S, T, topo.n_mixers), np.float32)
+    for t0 in range(0, T, chunk):
+        n = min(chunk, T - t0)
+        for s, (pred, act, ctx, bits) in enumerate(streams):
+            b.set_records(s, pred[t0:t0 + n], act[t0:t0 + n], ctx[t0:t0 + n], bits[t0:t0 + n])
+        b.upload(n)
+        g.run(b, n, learn=learn)
+        b.download(n)
+        b.wait()
+        P[:, t0:t0 + n] = b.p[:, :n]
+        O[:, t0:t0 + n] = b.outputs[:, :n]
+    return g, P, O
+
+
+@pytest.mark.parametrize("kw,mask", [
+    (dict(ctx_mode=0), True),                                  # every row changes every bit
+    (dict(ctx_mode=3, ctx_mod=5, zero_mod=7, bit_mode=1), True),  # rows persist, silent models, learnable
+    (dict(ctx_mode=1, ctx_mod=2, bit_mode=1), False),           # >1024 visits per row: shrink; no mask
+])
+def test_stock_kernel_equals_general_kernel_and_oracle(gpu, oracle, kw, mask):
+    topo = topology.stock(90)
+    S, T = 5, 2600
+    streams = [oracle.synth(90, 33, T, seed=1234 + 17 * s, **kw) for s in range(S)]
+    g1, P1, O1 = run(gpu, topo, streams, 700, force_general=False, mask=mask)
+    g2, P2, O2 = run(gpu, topo, streams, 700, force_general=True, mask=mask)
+    assert beq(P1, P2) and beq(O1, O2)
+    for s in range(S):
+        assert g1.export(s) == g2.export(s)
+    ob = oracle.Bank(90, topo.skip, topo.mixers)
+    p_ref, o_ref = ob.run(*streams[2])
+    assert beq(O1[2], o_ref) and beq(P1[2], p_ref)
+    assert g1.export(2) == (ob.export_long(), ob.export_short())
+    g1.close()
+    g2.close()
+
+
+def test_stock_kernel_forward_only_and_per_bit(gpu, oracle):
+    topo = topology.stock(90)
+    T = 500
+    pred, act, ctx, bits = oracle.synth(90, 33, T, seed=77, ctx_mode=3, ctx_mod=6, zero_mod=9, bit_mode=1)
+    ob = oracle.Bank(90, topo.skip, topo.mixers)
+    p_ref, o_ref = ob.run(pred, act, ctx, bits, nolearn_from=400)
+    g, P, O = run(gpu, topo, [(pred[:400], act[:400], ctx[:400], bits[:400])], 400, False)
+    assert beq(P[0], p_ref[:400])
+    before = g.export(0)
+    for t in range(400, T):  # Predict without Learn through the per-bit surface
+        idx = np.nonzero(act[t])[0].astype(np.int32)
+        p, out = g.forward(pred[t], idx, ctx[t])
+        assert beq(out, o_ref[t]) and np.float32(p).view(np.uint32) == p_ref[t].view(np.uint32), t
+    assert g.export(0) == before
+    g.close()
