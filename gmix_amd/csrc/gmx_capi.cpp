@@ -9,8 +9,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <new>
 #include <string>
@@ -85,6 +87,8 @@ struct gmx_group {
   size_t decay_cap = 0;            // floats
   gmx_batch* one = nullptr;        // 1-bit batch (one record per stream) of the per-bit surface
   std::vector<gmx_batch*> batches; // live batches; orphaned (b->g = nullptr) when the group dies
+  std::vector<struct GmxSession*> sessions;  // per stream, lazily: persistent per-bit kernels
+  bool use_sessions = true;        // tests: per-bit calls as two launches instead of a session
   bool force_general = false;      // tests: route everything through the general kernel
   int single_variant = 0;          // tests/tuning: lanes per stream of the single-mixer kernel (0 = default)
 };
@@ -114,6 +118,10 @@ struct gmx_batch {
   float* h_p = nullptr;
   float* h_out = nullptr;
 };
+
+// per-bit sessions (gmx_session.inc)
+static int sessions_close(gmx_group* g, bool keep_forward);
+static void sessions_free(gmx_group* g);
 
 extern "C" const char* gmx_strerror(int status) {
   switch (status) {
@@ -302,6 +310,7 @@ extern "C" int gmx_group_create(gmx_group** out, const gmx_topology* topo, int n
 extern "C" void gmx_group_destroy(gmx_group* g) {
   if (!g) return;
   (void)hipSetDevice(g->device);
+  sessions_free(g);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   if (g->one) {
     batch_free(g->one);
@@ -332,6 +341,8 @@ extern "C" uint64_t gmx_group_bank_bytes(const gmx_group* g) { return g ? g->top
 extern "C" int gmx_group_reset(gmx_group* g) {
   if (!g) return GMX_ERR_INVALID;
   HIPCHK(hipSetDevice(g->device));
+  int rc = sessions_close(g, false);
+  if (rc) return rc;
   HIPCHK(hipMemsetAsync(g->banks, 0, (size_t)g->S * g->topo.bank_bytes, g->stream));
   HIPCHK(gmx_launch_init_scal(g->banks, g->topo.bank_bytes, g->topo.scal_off, g->topo.m, g->S,
                               g->stream));
@@ -344,6 +355,8 @@ extern "C" int gmx_group_reset(gmx_group* g) {
 extern "C" int gmx_group_sync(gmx_group* g) {
   if (!g) return GMX_ERR_INVALID;
   HIPCHK(hipSetDevice(g->device));
+  int rc = sessions_close(g, true);  // per-bit work is part of "everything submitted so far"
+  if (rc) return rc;
   HIPCHK(hipStreamSynchronize(g->stream));
   return GMX_OK;
 }
@@ -353,6 +366,8 @@ extern "C" int gmx_group_sync(gmx_group* g) {
 // with the same libm pow the reference calls and ships it with the records; the per-row
 // second factor (mixer.cpp:112) is IEEE double arithmetic and stays on the device.
 static float decay_base(uint64_t steps) { return (float)(0.9 / pow(0.0000001 * steps + 0.8, 0.8)); }
+
+#include "gmx_session.inc"
 
 // Fill the group's decay tables for a run of T learning bits over streams [s0, s0+ns).
 static int prepare_decay(gmx_group* g, int s0, int ns, uint64_t T, int learn) {
@@ -639,6 +654,8 @@ extern "C" int gmx_batch_fill_synthetic(gmx_batch* b, uint64_t n_bits, uint64_t 
 extern "C" int gmx_group_run(gmx_group* g, gmx_batch* b, uint64_t n_bits, int learn, float* kernel_ms) {
   if (!g || !b || b->g != g || b->S != g->S || n_bits > b->max_bits) return GMX_ERR_INVALID;
   HIPCHK(hipSetDevice(g->device));
+  int rc = sessions_close(g, false);
+  if (rc) return rc;
   std::fill(g->fwd_done.begin(), g->fwd_done.end(), 0);
   return launch_run(g, b, 0, 0, g->S, n_bits, GMX_MODE_PREDICT | (learn ? GMX_MODE_LEARN : 0u),
                     kernel_ms);
@@ -663,7 +680,15 @@ extern "C" int gmx_bank_forward(gmx_group* g, int stream, const float* predictio
   if (!g || stream < 0 || stream >= g->S || !predictions || !contexts) return GMX_ERR_INVALID;
   if (n_active > 0 && !active_models) return GMX_ERR_INVALID;
   HIPCHK(hipSetDevice(g->device));
-  int rc = ensure_one(g);
+  int rc;
+  if (g->use_sessions && group_is_stock(g)) {
+    rc = session_forward(g, stream, predictions, active_models, n_active, contexts, p_final, out_all);
+    if (rc == GMX_OK) g->fwd_done[stream] = 2;
+    if (rc != GMX_ERR_STATE) return rc;  // GMX_ERR_STATE: no session slot, two launches instead
+  }
+  rc = sessions_close(g, true);
+  if (rc) return rc;
+  rc = ensure_one(g);
   if (rc) return rc;
   gmx_batch* b = g->one;
   const GmxTopoDev& t = g->topo;
@@ -704,8 +729,14 @@ extern "C" int gmx_bank_forward(gmx_group* g, int stream, const float* predictio
 
 extern "C" int gmx_bank_learn(gmx_group* g, int stream, int bit) {
   if (!g || stream < 0 || stream >= g->S || (bit != 0 && bit != 1)) return GMX_ERR_INVALID;
-  if (!g->one || !g->fwd_done[stream]) return GMX_ERR_STATE;
+  if (!g->fwd_done[stream]) return GMX_ERR_STATE;
   HIPCHK(hipSetDevice(g->device));
+  if (g->fwd_done[stream] == 2) {
+    int rcs = session_learn(g, stream, bit);
+    if (rcs == GMX_OK) g->fwd_done[stream] = 0;
+    return rcs;
+  }
+  if (!g->one) return GMX_ERR_STATE;
   gmx_batch* b = g->one;
   HIPCHK(hipStreamSynchronize(g->stream));
   b->h_bits[stream] = (uint8_t)bit;
@@ -721,6 +752,8 @@ extern "C" int gmx_bank_learn(gmx_group* g, int stream, int bit) {
 static int fetch_bank(gmx_group* g, int stream, std::vector<uint8_t>& img) {
   img.resize(g->topo.bank_bytes);
   HIPCHK(hipSetDevice(g->device));
+  int rc = sessions_close(g, true);
+  if (rc) return rc;
   HIPCHK(hipStreamSynchronize(g->stream));
   HIPCHK(hipMemcpy(img.data(), g->banks + (size_t)stream * g->topo.bank_bytes, img.size(),
                    hipMemcpyDeviceToHost));
@@ -809,6 +842,9 @@ extern "C" int gmx_bank_import(gmx_group* g, int stream, const void* long_buf, s
   }
   if (p != end) return GMX_ERR_FORMAT;
   HIPCHK(hipSetDevice(g->device));
+  int rc = sessions_close(g, true);
+  if (rc) return rc;
+  if (stream < (int)g->sessions.size() && g->sessions[stream]) g->sessions[stream]->fwd_live = false;
   HIPCHK(hipStreamSynchronize(g->stream));
   HIPCHK(hipMemcpy(g->banks + (size_t)stream * t.bank_bytes, img.data(), img.size(),
                    hipMemcpyHostToDevice));
@@ -828,8 +864,14 @@ extern "C" int gmx_bank_copy(gmx_group* dst, int dst_stream, gmx_group* src, int
         a.mx[j].layer != b.mx[j].layer)
       return GMX_ERR_INVALID;
   HIPCHK(hipSetDevice(src->device));
+  int rc = sessions_close(src, true);
+  if (rc) return rc;
   HIPCHK(hipStreamSynchronize(src->stream));
   HIPCHK(hipSetDevice(dst->device));
+  rc = sessions_close(dst, true);
+  if (rc) return rc;
+  if (dst_stream < (int)dst->sessions.size() && dst->sessions[dst_stream])
+    dst->sessions[dst_stream]->fwd_live = false;
   HIPCHK(hipStreamSynchronize(dst->stream));
   HIPCHK(hipMemcpy(dst->banks + (size_t)dst_stream * a.bank_bytes,
                    src->banks + (size_t)src_stream * b.bank_bytes, a.bank_bytes,
@@ -843,6 +885,8 @@ extern "C" int gmx_bank_memory_usage(gmx_group* g, int stream, int mixer, uint64
   if (!g || stream < 0 || stream >= g->S || mixer < 0 || mixer >= g->topo.m || !bytes)
     return GMX_ERR_INVALID;
   HIPCHK(hipSetDevice(g->device));
+  int rc = sessions_close(g, true);
+  if (rc) return rc;
   HIPCHK(hipStreamSynchronize(g->stream));
   uint64_t sc[3];
   HIPCHK(hipMemcpy(sc, g->banks + (size_t)stream * g->topo.bank_bytes + g->topo.scal_off + 24u * mixer,
@@ -865,6 +909,48 @@ extern "C" int gmx_debug_single_variant(gmx_group* g, int lanes_per_stream) {
 extern "C" int gmx_debug_force_general(gmx_group* g, int on) {
   if (!g) return GMX_ERR_INVALID;
   g->force_general = on != 0;
+  return GMX_OK;
+}
+
+// Per-bit calls as two kernel launches (on != 0: sessions allowed, the default).
+extern "C" int gmx_debug_use_sessions(gmx_group* g, int on) {
+  if (!g) return GMX_ERR_INVALID;
+  int rc = sessions_close(g, true);
+  if (rc) return rc;
+  for (GmxSession* se : g->sessions)
+    if (se && se->fwd_live) return GMX_ERR_STATE;  // not between a forward and its learn
+  g->use_sessions = on != 0;
+  return GMX_OK;
+}
+
+extern "C" int gmx_debug_open_sessions(void) { return g_open_sessions.load(); }
+
+// Wall-clock cost of n Predict+Learn pairs on `stream` through gmx_bank_forward / gmx_bank_learn
+// with made-up inputs (it trains the bank: use a scratch group).  ctx_hold = bits a context
+// stays (8 = byte-boundary contexts).
+extern "C" int gmx_debug_per_bit_latency(gmx_group* g, int stream, int n, int ctx_hold, double* us_per_bit) {
+  if (!g || n <= 0 || ctx_hold <= 0 || !us_per_bit) return GMX_ERR_INVALID;
+  const GmxTopoDev& t = g->topo;
+  std::vector<float> pred(t.n);
+  std::vector<uint32_t> ctx(t.m, 0);
+  uint64_t x = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&x]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  timespec a, b;
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < t.n; ++k) pred[k] = (float)((int64_t)(rnd() >> 40) - (1 << 23)) * (1.0f / (1 << 21));
+    if (i % ctx_hold == 0)
+      for (int k = 0; k < t.m; ++k) ctx[k] = (uint32_t)rnd();
+    float p;
+    int rc = gmx_bank_forward(g, stream, pred.data(), nullptr, -1, ctx.data(), &p, nullptr);
+    if (rc) return rc;
+    rc = gmx_bank_learn(g, stream, p > 0.5f ? 1 : 0);
+    if (rc) return rc;
+  }
+  int rc = gmx_group_sync(g);
+  if (rc) return rc;
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  *us_per_bit = ((b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3) / n;
   return GMX_OK;
 }
 

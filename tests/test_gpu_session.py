@@ -1,0 +1,167 @@
+"""The per-bit sessions (gmx_stock_session_kernel + gmx_session.inc): gmx_bank_forward /
+gmx_bank_learn through a persistent wave and a mailbox must give the floats and the state the
+batched kernels and the oracle give, whatever happens between two calls: the wave leaving on
+its idle timer, an export, a batched run, other streams taking its slot."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+from gmix_amd import topology
+
+pytestmark = pytest.mark.gpu
+
+
+def u32(x):
+    return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+def dbg(g):
+    g.L.gmx_debug_use_sessions.argtypes = [C.c_void_p, C.c_int]
+    g.L.gmx_debug_open_sessions.restype = C.c_int
+    return g.L
+
+
+def per_bit(g, rec, t0, t1, stream=0, hook=None):
+    pred, act, ctx, bits = rec
+    P = np.zeros(t1 - t0, np.float32)
+    O = np.zeros((t1 - t0, 33), np.float32)
+    for t in range(t0, t1):
+        idx = np.nonzero(act[t])[0].astype(np.int32)
+        P[t - t0], O[t - t0] = g.forward(pred[t], idx, ctx[t], stream=stream)
+        if hook:
+            hook(t, "mid")
+        g.learn(int(bits[t]), stream=stream)
+        if hook:
+            hook(t, "end")
+    return P, O
+
+
+@pytest.mark.parametrize("sessions", [True, False])
+def test_per_bit_equals_oracle_with_interruptions(gpu, oracle, sessions):
+    topo = topology.stock(90)
+    T = 1500
+    rec = oracle.synth(90, 33, T, seed=4242, ctx_mode=3, ctx_mod=5, zero_mod=7, bit_mode=1)
+    ob = oracle.Bank(90, topo.skip, topo.mixers)
+    p_ref, o_ref = ob.run(*rec)
+    g = gpu.MixerGroup(topo, 2)
+    L = dbg(g)
+    assert L.gmx_debug_use_sessions(g.h, 1 if sessions else 0) == 0
+    exports = []
+
+    def hook(t, where):
+        if t % 400 == 150 and where == "mid":
+            time.sleep(0.06)            # the wave leaves between Predict and Learn: replayed
+        if t % 400 == 250 and where == "end":
+            time.sleep(0.06)            # ... and between two bits
+        if t == 700 and where == "mid":
+            exports.append(g.export(0))  # stops the session, forward state must survive
+        if t == 900 and where == "end":
+            g.sync()
+            assert g.memory_usage(3) > 0
+
+    P, O = per_bit(g, rec, 0, T, stream=0, hook=hook)
+    assert np.array_equal(u32(O), u32(o_ref))
+    assert np.array_equal(u32(P), u32(p_ref))
+    assert g.export(0) == (ob.export_long(), ob.export_short())
+    ob2 = oracle.Bank(90, topo.skip, topo.mixers)
+    ob2.run(*[a[:700] for a in rec])
+    assert exports[0] == (ob2.export_long(), ob2.export_short())
+    assert L.gmx_debug_open_sessions() == 0  # the export closed it
+    g.close()
+
+
+def test_sessions_share_slots_and_interleave_with_batched_runs(gpu, oracle):
+    topo = topology.stock(90)
+    S, T = 5, 360
+    recs = [oracle.synth(90, 33, T, seed=99 + s, ctx_mode=2, ctx_mod=3, zero_mod=5, bit_mode=1) for s in range(S)]
+    refs = []
+    for s in range(S):
+        ob = oracle.Bank(90, topo.skip, topo.mixers)
+        refs.append((ob,) + ob.run(*recs[s]))
+    g = gpu.MixerGroup(topo, S)
+    L = dbg(g)
+    b = gpu.Batch(g, 120, outputs=True, mask=True)
+    # bits 0..119 batched
+    for s in range(S):
+        b.set_records(s, *[a[:120] for a in recs[s]])
+    b.upload(120)
+    g.run(b, 120, learn=True)
+    b.download(120)
+    b.wait()
+    for s in range(S):
+        assert np.array_equal(u32(b.outputs[s, :120]), u32(refs[s][2][:120]))
+    # bits 120..239 one at a time, all five streams in lock step: more sessions than slots,
+    # every Predict of a round is done before the first Learn (so evictions hit live forwards)
+    for t in range(120, 240):
+        for s in range(S):
+            pred, act, ctx, bits = recs[s]
+            p, o = g.forward(pred[t], np.nonzero(act[t])[0].astype(np.int32), ctx[t], stream=s)
+            assert np.array_equal(u32(o), u32(refs[s][2][t])), (t, s)
+            assert np.float32(p).view(np.uint32) == refs[s][1][t].view(np.uint32)
+        assert 1 <= L.gmx_debug_open_sessions() <= 3
+        for s in range(S):
+            g.learn(int(recs[s][3][t]), stream=s)
+    # bits 240..359 batched again: the sessions are closed first
+    for s in range(S):
+        b.set_records(s, *[a[240:360] for a in recs[s]])
+    b.upload(120)
+    g.run(b, 120, learn=True)
+    assert L.gmx_debug_open_sessions() == 0
+    b.download(120)
+    b.wait()
+    for s in range(S):
+        assert np.array_equal(u32(b.outputs[s, :120]), u32(refs[s][2][240:360]))
+        assert g.export(s) == (refs[s][0].export_long(), refs[s][0].export_short())
+    b.close()
+    g.close()
+
+
+def test_two_groups_and_protocol_errors(gpu, oracle):
+    topo = topology.stock(90)
+    rec = oracle.synth(90, 33, 64, seed=5, ctx_mode=3, ctx_mod=4, bit_mode=1)
+    ob = oracle.Bank(90, topo.skip, topo.mixers)
+    p_ref, o_ref = ob.run(*rec)
+    ga, gb = gpu.MixerGroup(topo, 1), gpu.MixerGroup(topo, 1)
+    with pytest.raises(gpu.GmxError):
+        ga.learn(1)                      # Learn before any Predict
+    for t in range(64):
+        idx = np.nonzero(rec[1][t])[0].astype(np.int32)
+        pa, oa = ga.forward(rec[0][t], idx, rec[2][t])
+        pb, ob_ = gb.forward(rec[0][t], idx, rec[2][t])
+        assert np.array_equal(u32(oa), u32(o_ref[t])) and np.array_equal(u32(ob_), u32(o_ref[t]))
+        ga.learn(int(rec[3][t]))
+        gb.learn(int(rec[3][t]))
+        if t == 10:
+            with pytest.raises(gpu.GmxError):
+                ga.learn(0)              # a second Learn for the same Predict
+    assert ga.export(0) == gb.export(0) == (ob.export_long(), ob.export_short())
+    # copy a bank whose session is open into another group, continue there
+    gc = gpu.MixerGroup(topo, 1)
+    gc.copy_from(ga)
+    assert gc.export(0) == ga.export(0)
+    ga.close()
+    gb.close()
+    gc.close()
+
+
+def test_per_bit_latency_report(gpu, capsys):
+    """Not a parity test: records what a Predict+Learn pair costs through the C ABI."""
+    topo = topology.stock(90)
+    out = {}
+    for sessions in (1, 0):
+        g = gpu.MixerGroup(topo, 1)
+        L = dbg(g)
+        L.gmx_debug_per_bit_latency.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        assert L.gmx_debug_use_sessions(g.h, sessions) == 0
+        us = C.c_double()
+        assert L.gmx_debug_per_bit_latency(g.h, 0, 500, 8, C.byref(us)) == 0
+        for hold in (1, 8):
+            assert L.gmx_debug_per_bit_latency(g.h, 0, 4000, hold, C.byref(us)) == 0
+            out[sessions, hold] = us.value
+        g.close()
+    with capsys.disabled():
+        print(f"\n[per-bit Predict+Learn, C ABI] session: {out[1, 1]:.1f} us/bit (new rows every bit), "
+              f"{out[1, 8]:.1f} us/bit (contexts held 8 bits); two launches: {out[0, 1]:.1f} / {out[0, 8]:.1f} us/bit")
+    assert out[1, 8] < out[0, 8]
