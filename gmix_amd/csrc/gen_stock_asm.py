@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""Generates gmx_stock_asm.inc: the instruction streams of gmx_stock.hip's hot phases.
+
+Why generated assembly: a stream's bank of the stock topology is 174 MiB, so a full HBM holds
+about as many streams as the chip has SIMDs -- one wave per SIMD, and every instruction that
+wave issues, scalar or vector, is on the critical path.  hipcc's code for this arithmetic needs
+~2400 instructions per bit (selects with recomputed lane masks, SGPR spills through
+v_writelane, VGPR<->AGPR shuffling); the streams below need ~900 and perform the same IEEE
+operations in the same order (mul, then add -- never fused).
+
+Register map.  The kernels are compiled with amdgpu_num_vgpr(96) / amdgpu_num_sgpr(...) so
+that hipcc itself only allocates v0..v47, a0..a47 and the low SGPRs; everything above is
+reserved for the streams below and referenced by name (tests/test_abi.py checks that no
+compiler-generated instruction touches the reserved ranges):
+  X(j)  = v[48+j],  j = 0..91    the bit's inputs (broadcast-read from LDS)
+  W(j)  = v[140+j], j = 0..115   the lane's resident row (lane m = mixer m)
+  WN(j) = a[140+j]               the prefetched row (global loads land in AGPRs)
+  O0(i) = s[64+i],  i = 0..23    layer-0 outputs;  O1(i) = s[88+i], i = 0..7  layer-1 outputs
+
+Hazards honoured by construction (gfx940/gfx950; the spacing hipcc itself keeps):
+  VALU writes a VGPR -> v_readlane of it: >= 1 wait state;
+  v_readlane writes an SGPR -> VALU reads it: >= 2 wait states.
+"""
+import os
+
+XB, WB, AB, O0, O1 = 48, 140, 140, 64, 88
+N, L0, L1, M = 90, 24, 8, 33
+NQX = (N + 3) // 4   # 23 quads of inputs
+NQW = 29             # quads of a layer-0 row (113 weights); layer-1/final rows: 16 (64 floats stored)
+RESERVED = {"v": (48, 255), "a": (140, 255), "s": (64, 95)}
+
+
+def W(j):
+    return f"v{WB + j}"
+
+
+def W2(j):
+    assert j % 2 == 0
+    return f"v[{WB + j}:{WB + j + 1}]"
+
+
+def W4(q):
+    return f"v[{WB + 4 * q}:{WB + 4 * q + 3}]"
+
+
+def X(j):
+    return f"v{XB + j}"
+
+
+def X2(j):
+    return f"v[{XB + j}:{XB + j + 1}]"
+
+
+def X4(q):
+    return f"v[{XB + 4 * q}:{XB + 4 * q + 3}]"
+
+
+def A4(q):
+    return f"a[{AB + 4 * q}:{AB + 4 * q + 3}]"
+
+
+def emit(name, lines):
+    body = "".join(f'  "{l}\\n\\t" \\\n' for l in lines)
+    return f"#define {name} \\\n{body}  \"\"\n\n"
+
+
+def under_mask(body):
+    return ["s_mov_b64 %[sv], exec", "s_mov_b64 exec, %[mask]"] + body + ["s_mov_b64 exec, %[sv]"]
+
+
+def loads(first, last):
+    return under_mask([f"global_load_dwordx4 {A4(q)}, %[p], off offset:{16 * q}" for q in range(first, last)])
+
+
+def stores(first, last):
+    return under_mask([f"global_store_dwordx4 %[p], {W4(q)}, off offset:{16 * q}" for q in range(first, last)])
+
+
+def adopt(first, last):
+    return under_mask([f"v_accvgpr_read_b32 {W(j)}, a{AB + j}" for j in range(4 * first, 4 * last)])
+
+
+def load_x(l, consume):
+    """Broadcast-read the 23 input quads from LDS into X, at most `depth` reads in flight
+    (lgkmcnt is a 4-bit counter); consume(q) emits the work that needs quad q."""
+    depth = 8
+    l.append("s_waitcnt lgkmcnt(0)")
+    for q in range(min(depth, NQX)):
+        l.append(f"ds_read_b128 {X4(q)}, %[xaddr] offset:{16 * q}")
+    for q in range(NQX):
+        issued = min(NQX, q + depth)
+        l.append(f"s_waitcnt lgkmcnt({issued - q - 1})")
+        if q + depth < NQX:
+            l.append(f"ds_read_b128 {X4(q + depth)}, %[xaddr] offset:{16 * (q + depth)}")
+        consume(q)
+
+
+def chain_l0(l, with_loads=True):
+    """layer 0, inputs 0..89 (mixer.cpp:56-59): acc = acc + x*w, left to right"""
+    def consume(q):
+        for e in range(4):
+            j = 4 * q + e
+            if j < N:
+                t = "%[t0]" if j % 2 == 0 else "%[t1]"
+                l.append(f"v_mul_f32 {t}, {X(j)}, {W(j)}")
+                l.append(f"v_add_f32 %[acc], %[acc], {t}")
+    if with_loads:
+        load_x(l, consume)
+    else:
+        for q in range(NQX):
+            consume(q)
+
+
+def forward():
+    """33 x Mixer::Predict (mixer.cpp:51-106), every lane its own mixer.  A lane that takes no
+    part in a step sees a zero weight there (the stored padding beyond weight_size; a row never
+    learned is all zeros), so `acc + o*0` leaves it alone -- exact as long as every value is
+    finite, which the kernel checks afterwards (else it redoes the bit with forward_exact)."""
+    l = ["v_mov_b32 %[acc], 0", "v_mov_b32 %[a1], 0"]
+    chain_l0(l)
+    # layer-0 cascade (mixer.cpp:60-64) merged with the sums of layer 1 / final over the
+    # layer-0 outputs (mixer.cpp:66-68, 82-84): O0(i) is read once and feeds both
+    for i in range(L0):
+        if i >= 1:
+            l.append(f"v_mul_f32 %[t1], s{O0 + i - 1}, {W(i - 1)}")
+        else:
+            l.append("s_nop 0")
+        l.append(f"v_readlane_b32 s{O0 + i}, %[acc], {i}")
+        if i >= 1:
+            l.append("v_add_f32 %[a1], %[a1], %[t1]")
+            l.append("s_nop 0")
+        else:
+            l.append("s_nop 1")
+        if i < L0 - 1:
+            l.append(f"v_mul_f32 %[t0], s{O0 + i}, {W(N + i)}")
+            l.append("v_add_f32 %[acc], %[acc], %[t0]")
+    l.append(f"v_mul_f32 %[t1], s{O0 + L0 - 1}, {W(L0 - 1)}")
+    l.append("v_add_f32 %[a1], %[a1], %[t1]")
+    # From here on %[a1] is the running sum of lanes 24..32 (garbage in the layer-0 lanes, whose
+    # outputs stay in %[acc]).  Layer-1 cascade, each mixer's skip input closing its chain
+    # (mixer.cpp:69-80); lane 32, the final mixer, collects the layer-1 outputs on the way
+    # (mixer.cpp:85-90).
+    l.append("s_mov_b32 vcc_hi, 0")
+    for i in range(L1):
+        l.append(f"v_mul_f32 %[t0], %[vskip], {W(L0 + i)}")
+        l.append("v_add_f32 %[t1], %[a1], %[t0]")
+        l.append(f"s_mov_b32 vcc_lo, {hex(1 << (L0 + i))}")
+        l.append(f"v_readlane_b32 s{O1 + i}, %[t1], {L0 + i}")
+        l.append("s_nop 1")
+        l.append(f"v_mul_f32 %[t0], s{O1 + i}, {W(L0 + i)}")
+        l.append("v_add_f32 %[t0], %[a1], %[t0]")
+        l.append("v_cndmask_b32 %[a1], %[t0], %[t1], vcc")
+    # the final mixer's skip input (mixer.cpp:91-97); weight 32 of the layer-1 lanes is padding
+    l.append(f"v_mul_f32 %[t0], %[vskip], {W(L0 + L1)}")
+    l.append("v_add_f32 %[a1], %[a1], %[t0]")
+    l.append("s_mov_b32 vcc_lo, 0xffffff")
+    l.append("v_cndmask_b32 %[acc], %[a1], %[acc], vcc")
+    return l
+
+
+def forward_exact():
+    """The same chains with every step under the exec mask of the lanes the reference visits
+    (and only rows that exist, mixer.cpp:52-55): no value reaches a lane it does not belong to,
+    whatever it is.  Slower (more scalar instructions); used when forward() met a non-finite."""
+    l = ["v_mov_b32 %[acc], 0", "v_mov_b32 %[a1], 0"]
+    load_x(l, lambda q: None)  # X in every lane: the update reads it in all layer-0 lanes
+    l.append("s_mov_b64 %[sv], exec")
+    l.append("s_and_b32 exec_lo, %[seenlo], 0xffffff")
+    l.append("s_mov_b32 exec_hi, 0")
+    chain_l0(l, with_loads=False)
+    for i in range(L0):
+        l.append("s_nop 0")
+        l.append(f"v_readlane_b32 s{O0 + i}, %[acc], {i}")
+        if i < L0 - 1:
+            l.append(f"s_and_b32 exec_lo, %[seenlo], {hex(0xffffff & ~((2 << i) - 1))}")
+            l.append("s_nop 0")
+            l.append(f"v_mul_f32 %[t0], s{O0 + i}, {W(N + i)}")
+            l.append("v_add_f32 %[acc], %[acc], %[t0]")
+    l.append("s_and_b32 exec_lo, %[seenlo], 0xff000000")
+    l.append("s_and_b32 exec_hi, %[seenhi], 1")
+    for i in range(L0):
+        t = "%[t0]" if i % 2 == 0 else "%[t1]"
+        l.append(f"v_mul_f32 {t}, s{O0 + i}, {W(i)}")
+        l.append(f"v_add_f32 %[a1], %[a1], {t}")
+    for i in range(L1):
+        l.append(f"s_and_b32 exec_lo, %[seenlo], {hex(1 << (L0 + i))}")
+        l.append("s_mov_b32 exec_hi, 0")
+        l.append(f"v_mul_f32 %[t0], %[vskip], {W(L0 + i)}")
+        l.append("v_add_f32 %[a1], %[a1], %[t0]")
+        l.append("s_nop 0")
+        l.append(f"v_readlane_b32 s{O1 + i}, %[a1], {L0 + i}")
+        l.append(f"s_and_b32 exec_lo, %[seenlo], {hex(0xff000000 & ~((2 << (L0 + i)) - 1))}")
+        l.append("s_and_b32 exec_hi, %[seenhi], 1")
+        l.append(f"v_mul_f32 %[t0], s{O1 + i}, {W(L0 + i)}")
+        l.append("v_add_f32 %[a1], %[a1], %[t0]")
+    l.append("s_mov_b32 exec_lo, 0")
+    l.append("s_and_b32 exec_hi, %[seenhi], 1")
+    l.append(f"v_mul_f32 %[t0], %[vskip], {W(L0 + L1)}")
+    l.append("v_add_f32 %[a1], %[a1], %[t0]")
+    l.append("s_mov_b64 exec, %[sv]")
+    l.append("s_mov_b32 vcc_lo, 0xffffff")
+    l.append("s_mov_b32 vcc_hi, 0")
+    l.append("v_cndmask_b32 %[acc], %[a1], %[acc], vcc")
+    return l
+
+
+def load_x_only():
+    l = []
+    load_x(l, lambda q: None)
+    return l
+
+
+def outputs_to_sgprs():
+    """O0/O1 from a per-lane vector of mixer outputs (learn-only launches of the per-bit API)."""
+    l = ["s_nop 0"]
+    for i in range(L0):
+        l.append(f"v_readlane_b32 s{O0 + i}, %[acc], {i}")
+    for i in range(L1):
+        l.append(f"v_readlane_b32 s{O1 + i}, %[acc], {L0 + i}")
+    l.append("s_nop 1")
+    return l
+
+
+def update():
+    """The weight sweeps of 33 x Mixer::Learn (mixer.cpp:129-172): w -= update * x (mul, then
+    subtract), lanes and elements selected with exec instead of per-element selects."""
+    l = ["s_mov_b64 %[sv], exec"]
+    # layer-0 lanes, inputs 0..89: two elements per instruction
+    l.append("s_mov_b64 exec, 0xffffff")
+    for j in range(0, N, 2):
+        t = "%[p0]" if (j // 2) % 2 == 0 else "%[p1]"
+        l.append(f"v_pk_mul_f32 {t}, {X2(j)}, %[up2]")
+        l.append(f"v_pk_add_f32 {W2(j)}, {W2(j)}, {t} neg_lo:[0,1] neg_hi:[0,1]")
+    # layer-0 lanes, weight 90+i multiplies the output of mixer i, lanes i+1..23 only
+    for i in range(L0 - 1):
+        t = "%[t0]" if i % 2 == 0 else "%[t1]"
+        l.append(f"s_bitset0_b32 exec_lo, {i}")
+        l.append(f"v_mul_f32 {t}, s{O0 + i}, %[upd]")
+        l.append(f"v_sub_f32 {W(N + i)}, {W(N + i)}, {t}")
+    # layer-1 and final lanes: the 24 layer-0 outputs
+    l.append("s_mov_b32 exec_lo, 0xff000000")
+    l.append("s_mov_b32 exec_hi, 1")
+    l.append("v_mul_f32 %[ts], %[vskip], %[upd]")
+    for j in range(0, L0, 2):
+        t = "%[p0]" if (j // 2) % 2 == 0 else "%[p1]"
+        l.append(f"v_pk_mul_f32 {t}, s[{O0 + j}:{O0 + j + 1}], %[up2]")
+        l.append(f"v_pk_add_f32 {W2(j)}, {W2(j)}, {t} neg_lo:[0,1] neg_hi:[0,1]")
+    # weight 24+i multiplies layer-1 output i, lanes 24+i+1..32 only
+    for i in range(L1):
+        t = "%[t0]" if i % 2 == 0 else "%[t1]"
+        l.append(f"s_bitset0_b32 exec_lo, {L0 + i}")
+        l.append(f"v_mul_f32 {t}, s{O1 + i}, %[upd]")
+        l.append(f"v_sub_f32 {W(L0 + i)}, {W(L0 + i)}, {t}")
+    # each mixer's own skip weight: lane 24+k holds it at index 24+k
+    l.append("s_mov_b32 exec_hi, 0")
+    for k in range(L1):
+        l.append(f"s_mov_b32 exec_lo, {hex(1 << (L0 + k))}")
+        l.append(f"v_sub_f32 {W(L0 + k)}, {W(L0 + k)}, %[ts]")
+    l.append("s_mov_b32 exec_lo, 0")
+    l.append("s_mov_b32 exec_hi, 1")
+    l.append(f"v_sub_f32 {W(L0 + L1)}, {W(L0 + L1)}, %[ts]")
+    l.append("s_mov_b64 exec, %[sv]")
+    return l
+
+
+def shrink():
+    """weights *= 1 - 3e-6 on every 1024th visit of a row (mixer.cpp:173-175); lanes whose row
+    is not due multiply by exactly 1.0f."""
+    return [f"v_pk_mul_f32 {W2(j)}, {W2(j)}, %[sc2]" for j in range(0, 4 * NQW, 2)]
+
+
+def zero_rows():
+    return [f"v_mov_b32 {W(j)}, 0" for j in range(4 * NQW)]
+
+
+def main():
+    blocks = {
+        "GMX_STK_LOAD_A": loads(0, 16), "GMX_STK_LOAD_B": loads(16, NQW),
+        "GMX_STK_STORE_A": stores(0, 16), "GMX_STK_STORE_B": stores(16, NQW),
+        "GMX_STK_ADOPT_A": adopt(0, 16), "GMX_STK_ADOPT_B": adopt(16, NQW),
+        "GMX_STK_FORWARD": forward(), "GMX_STK_FORWARD_EXACT": forward_exact(),
+        "GMX_STK_LOAD_X": load_x_only(), "GMX_STK_OUTPUTS_TO_SGPRS": outputs_to_sgprs(),
+        "GMX_STK_UPDATE": update(), "GMX_STK_SHRINK": shrink(), "GMX_STK_ZERO": zero_rows(),
+    }
+    out = "// Generated by gen_stock_asm.py -- do not edit.\n\n"
+    for k, v in blocks.items():
+        out += emit(k, v)
+    out += f"#define GMX_STK_VGPR_LIMIT {RESERVED['v'][0]}\n"
+    out += f"#define GMX_STK_SGPR_FIRST {RESERVED['s'][0]}\n"
+    out += "// instructions: " + ", ".join(f"{k[8:].lower()} {len(v)}" for k, v in blocks.items()) + "\n"
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gmx_stock_asm.inc")
+    open(path, "w").write(out)
+    print({k[8:].lower(): len(v) for k, v in blocks.items()})
+
+
+if __name__ == "__main__":
+    main()

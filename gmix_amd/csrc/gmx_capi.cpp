@@ -90,6 +90,7 @@ struct gmx_group {
   std::vector<struct GmxSession*> sessions;  // per stream, lazily: persistent per-bit kernels
   bool use_sessions = true;        // tests: per-bit calls as two launches instead of a session
   bool force_general = false;      // tests: route everything through the general kernel
+  bool stock_exact = false;        // tests: stock kernels use their masked forward chains only
   int single_variant = 0;          // tests/tuning: lanes per stream of the single-mixer kernel (0 = default)
 };
 
@@ -436,7 +437,7 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
   a.latch_out = g->latch_out;
   a.rec_stride = b->max_bits;
   a.T = T;
-  a.mode = mode;
+  a.mode = mode | (g->stock_exact ? GMX_MODE_EXACT : 0u);
   a.stream_base = s0;
   a.rec_base = rec0;
   a.n_streams = ns;
@@ -909,6 +910,16 @@ extern "C" int gmx_debug_single_variant(gmx_group* g, int lanes_per_stream) {
 extern "C" int gmx_debug_force_general(gmx_group* g, int on) {
   if (!g) return GMX_ERR_INVALID;
   g->force_general = on != 0;
+  return GMX_OK;
+}
+
+// Stock kernels: only the masked (exec-per-step) forward chains, which are otherwise the
+// fallback for non-finite values.
+extern "C" int gmx_debug_stock_exact(gmx_group* g, int on) {
+  if (!g) return GMX_ERR_INVALID;
+  int rc = sessions_close(g, true);
+  if (rc) return rc;
+  g->stock_exact = on != 0;
   return GMX_OK;
 }
 

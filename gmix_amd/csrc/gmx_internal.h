@@ -11,6 +11,7 @@
 #define GMX_MODE_PREDICT 1u   // run the forward chain (else: outputs come from the latch)
 #define GMX_MODE_LEARN 2u     // run Mixer::Learn after each bit
 #define GMX_MODE_LATCH 4u     // forward-only call of the per-bit surface: keep outputs for learn
+#define GMX_MODE_EXACT 8u     // stock kernels: masked forward chains only (tests; see gmx_stock.hip)
 
 // Device-side description of one Mixer (mixer.h:33-38 + where its table lives in a bank).
 struct GmxMixerDev {

@@ -15,11 +15,13 @@ def beq(a, b):
                           np.ascontiguousarray(b, np.float32).view(np.uint32))
 
 
-def run(gpu, topo, streams, chunk, force_general, mask=True, learn=True):
+def run(gpu, topo, streams, chunk, force_general, mask=True, learn=True, exact=False):
     S, T = len(streams), len(streams[0][3])
     g = gpu.MixerGroup(topo, S)
     g.L.gmx_debug_force_general.argtypes = [C.c_void_p, C.c_int]
     g.L.gmx_debug_force_general(g.h, 1 if force_general else 0)
+    g.L.gmx_debug_stock_exact.argtypes = [C.c_void_p, C.c_int]
+    assert g.L.gmx_debug_stock_exact(g.h, 1 if exact else 0) == 0
     b = gpu.Batch(g, chunk, outputs=True, mask=mask)
     P = np.zeros((S, T), np.float32)
     O = np.zeros((S, T, topo.n_mixers), np.float32)
@@ -54,8 +56,41 @@ def test_stock_kernel_equals_general_kernel_and_oracle(gpu, oracle, kw, mask):
     p_ref, o_ref = ob.run(*streams[2])
     assert beq(O1[2], o_ref) and beq(P1[2], p_ref)
     assert g1.export(2) == (ob.export_long(), ob.export_short())
+    # the masked forward chains (the fallback for non-finite values) give the same floats
+    g3, P3, O3 = run(gpu, topo, streams, 700, force_general=False, mask=mask, exact=True)
+    assert beq(P1, P3) and beq(O1, O3)
+    for s in range(S):
+        assert g1.export(s) == g3.export(s)
     g1.close()
     g2.close()
+    g3.close()
+
+
+def test_stock_kernel_non_finite_values_stay_where_the_reference_puts_them(gpu, oracle):
+    """An infinite input reaches every mixer whose row exists -- and only those: a mixer on a row
+    it has never learned still predicts exactly 0 (mixer.cpp:52-55).  The fast chains would
+    smear NaN over such lanes through their zero weights; the kernel must notice and redo the
+    bit with the masked chains."""
+    topo = topology.stock(90)
+    T = 260
+    pred, act, ctx, bits = oracle.synth(90, 33, T, seed=909, ctx_mode=3, ctx_mod=4, bit_mode=1)
+    pred = pred.copy()
+    act = act.copy()
+    ctx = ctx.copy()
+    pred[200, 7] = np.inf           # an active input blows up at bit 200 ...
+    act[200, 7] = 1
+    ctx[200:, 3] = 0x12345          # ... while mixer 3 moves to a row it has never seen
+    ob = oracle.Bank(90, topo.skip, topo.mixers)
+    p_ref, o_ref = ob.run(pred[:201], act[:201], ctx[:201], bits[:201], nolearn_from=200)
+    g, P, O = run(gpu, topo, [(pred[:200], act[:200], ctx[:200], bits[:200])], 200, False)
+    assert beq(O[0], o_ref[:200])
+    idx = np.nonzero(act[200])[0].astype(np.int32)
+    p, out = g.forward(pred[200], idx, ctx[200])
+    assert out[3] == 0.0 and o_ref[200][3] == 0.0
+    fin = np.isfinite(o_ref[200])
+    assert np.array_equal(np.isfinite(out), fin) and not fin.all()
+    assert beq(out[fin], o_ref[200][fin])
+    g.close()
 
 
 def test_stock_kernel_forward_only_and_per_bit(gpu, oracle):
