@@ -9,9 +9,10 @@ v_writelane, VGPR<->AGPR shuffling); the streams below need ~900 and perform the
 operations in the same order (mul, then add -- never fused).
 
 Register map.  The kernels are compiled with amdgpu_num_vgpr(96) / amdgpu_num_sgpr(...) so
-that hipcc itself only allocates v0..v47, a0..a47 and the low SGPRs; everything above is
+that hipcc itself only allocates v0..v43, a0..a43 and the low SGPRs; everything above is
 reserved for the streams below and referenced by name (tests/test_abi.py checks that no
 compiler-generated instruction touches the reserved ranges):
+  v44..v47                       temporaries of the streams
   X(j)  = v[48+j],  j = 0..91    the bit's inputs (broadcast-read from LDS)
   W(j)  = v[140+j], j = 0..115   the lane's resident row (lane m = mixer m)
   WN(j) = a[140+j]               the prefetched row (global loads land in AGPRs)
@@ -23,11 +24,12 @@ Hazards honoured by construction (gfx940/gfx950; the spacing hipcc itself keeps)
 """
 import os
 
-XB, WB, AB, O0, O1 = 48, 140, 140, 64, 88
+TB, XB, WB, AB, O0, O1 = 44, 48, 140, 140, 64, 88
 N, L0, L1, M = 90, 24, 8, 33
 NQX = (N + 3) // 4   # 23 quads of inputs
-NQW = 29             # quads of a layer-0 row (113 weights); layer-1/final rows: 16 (64 floats stored)
-RESERVED = {"v": (48, 255), "a": (140, 255), "s": (64, 95)}
+NQW = 29             # quads of a layer-0 row (113 weights)
+NQA = 9              # quads of a layer-1 / final row that hold weights (33 of the 64 floats stored)
+RESERVED = {"v": (44, 255), "a": (140, 255), "s": (64, 95)}
 
 
 def W(j):
@@ -98,12 +100,15 @@ def load_x(l, consume):
 def chain_l0(l, with_loads=True):
     """layer 0, inputs 0..89 (mixer.cpp:56-59): acc = acc + x*w, left to right"""
     def consume(q):
-        for e in range(4):
-            j = 4 * q + e
+        # products two at a time (same IEEE multiply), the sum strictly one after the other
+        for h in range(2):
+            j = 4 * q + 2 * h
             if j < N:
-                t = "%[t0]" if j % 2 == 0 else "%[t1]"
-                l.append(f"v_mul_f32 {t}, {X(j)}, {W(j)}")
-                l.append(f"v_add_f32 %[acc], %[acc], {t}")
+                t = TB + 2 * ((j // 2) % 2)
+                l.append(f"v_pk_mul_f32 v[{t}:{t + 1}], {X2(j)}, {W2(j)}")
+                l.append(f"v_add_f32 %[acc], %[acc], v{t}")
+                if j + 1 < N:
+                    l.append(f"v_add_f32 %[acc], %[acc], v{t + 1}")
     if with_loads:
         load_x(l, consume)
     else:
@@ -275,9 +280,11 @@ def zero_rows():
 
 def main():
     blocks = {
-        "GMX_STK_LOAD_A": loads(0, 16), "GMX_STK_LOAD_B": loads(16, NQW),
-        "GMX_STK_STORE_A": stores(0, 16), "GMX_STK_STORE_B": stores(16, NQW),
-        "GMX_STK_ADOPT_A": adopt(0, 16), "GMX_STK_ADOPT_B": adopt(16, NQW),
+        # part A: chunks every row has weights in (layer 1 / final: 33 weights = 9 chunks; what they
+        # store beyond is padding that is zero in HBM and in the registers); part B: layer 0 only
+        "GMX_STK_LOAD_A": loads(0, NQA), "GMX_STK_LOAD_B": loads(NQA, NQW),
+        "GMX_STK_STORE_A": stores(0, NQA), "GMX_STK_STORE_B": stores(NQA, NQW),
+        "GMX_STK_ADOPT_A": adopt(0, NQA), "GMX_STK_ADOPT_B": adopt(NQA, NQW),
         "GMX_STK_FORWARD": forward(), "GMX_STK_FORWARD_EXACT": forward_exact(),
         "GMX_STK_LOAD_X": load_x_only(), "GMX_STK_OUTPUTS_TO_SGPRS": outputs_to_sgprs(),
         "GMX_STK_UPDATE": update(), "GMX_STK_SHRINK": shrink(), "GMX_STK_ZERO": zero_rows(),

@@ -10,7 +10,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIMIT = {"v": 48, "a": 48, "s": 64}
+LIMIT = {"v": 44, "a": 44, "s": 64}
 
 
 def compile_to_asm():
