@@ -39,7 +39,7 @@ def make_topology(name):
     raise SystemExit(f"unknown --config {name}")
 
 
-def cpu_baseline(topo, sample_bits):
+def cpu_baseline(topo, sample_bits, ctx_mode=0, ctx_mod=1):
     """Reference Mixer (oracle/_ref, kind 'reference') or the C restatement (kind 'port'),
     single thread, on a bounded sample of the same workload."""
     spec = ",".join(f"{l}:{t}:{lr!r}" for l, t, lr in topo.mixers)
@@ -47,7 +47,8 @@ def cpu_baseline(topo, sample_bits):
     ncpu = os.cpu_count()
     if os.path.exists(exe):
         try:
-            out = subprocess.run([exe, "--n", str(topo.n_inputs), "--topo", spec, "--bits", str(sample_bits)],
+            out = subprocess.run([exe, "--n", str(topo.n_inputs), "--topo", spec, "--bits", str(sample_bits),
+                                  "--ctx-mode", str(ctx_mode), "--ctx-mod", str(ctx_mod)],
                                  capture_output=True, text=True, timeout=600, check=True).stdout
             r = json.loads(out.strip().splitlines()[-1])
             return {"value": r["bits_per_s"], "unit": "bits/s", "cores": 1, "kind": "reference",
@@ -56,7 +57,7 @@ def cpu_baseline(topo, sample_bits):
         except Exception as e:  # fall through to the port
             sys.stderr.write(f"[bench] reference baseline failed: {e}\n")
     from oracle import gmxo
-    pred, act, ctx, bits = gmxo.synth(topo.n_inputs, topo.n_mixers, sample_bits)
+    pred, act, ctx, bits = gmxo.synth(topo.n_inputs, topo.n_mixers, sample_bits, ctx_mode=ctx_mode, ctx_mod=ctx_mod)
     b = gmxo.Bank(topo.n_inputs, topo.skip, topo.mixers)
     t0 = time.perf_counter()
     b.run(pred, act, ctx, bits, want_all=False)
@@ -149,14 +150,19 @@ def main():
         bits_per_step = S * T * n_gpus
         value = bits_per_step * steps / elapsed
         avg_ms = sum(kernel_ms) / len(kernel_ms)
-        bytes_per_launch = topo.bytes_per_bit() * S * T
+        # rows move when a gate context changes: every bit (ctx-mode 0/1) or every 8th bit (2/3)
+        row_bytes = 8 * sum(topo.weight_sizes())
+        hold = 8 if args.ctx_mode >= 2 else 1
+        bytes_per_bit = row_bytes // hold + topo.bytes_per_bit() - row_bytes
+        bytes_per_launch = bytes_per_bit * S * T
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         out = {
             "metric": "mixer bits/sec (synthetic 256-input mixer streams, forward+update)",
             "value": value, "unit": "bits/s", "n_gpus": n_gpus, "steps": steps, "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "n_inputs": topo.n_inputs,
+            "config": {"workload": workload + ("" if hold == 1 else ", gate contexts redrawn every 8th bit"),
+                       "n_inputs": topo.n_inputs,
                        "mixers": f"{topo.l0}/{topo.l1}/{1 if topo.has_final else 0}",
                        "streams_per_gpu": S, "bits_per_stream_per_step": T,
                        "bits_per_step": bits_per_step, "total_bits": bits_per_step * steps,
@@ -166,7 +172,7 @@ def main():
                          "kernel": ("gmx_single_kernel" if topo.n_mixers == 1 else
                                     "gmx_stock_kernel" if args.config == "stock" else "gmx_bank_kernel"),
                          "kernel_ms_avg": avg_ms,
-                         "algorithmic_bytes_per_bit": topo.bytes_per_bit(),
+                         "algorithmic_bytes_per_bit": bytes_per_bit,
                          "bytes_per_launch": bytes_per_launch},
         }
         # HBM traffic per launch comes from rocprofv3 PMC passes of this same command (they
@@ -184,7 +190,8 @@ def main():
         except Exception as e:
             sys.stderr.write(f"[bench] no PMC summary: {e}\n")
         if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(topo, args.cpu_sample_bits)
+            sample = args.cpu_sample_bits if topo.n_mixers == 1 else min(args.cpu_sample_bits, 400_000)
+            out["cpu_baseline"] = cpu_baseline(topo, sample, args.ctx_mode, args.ctx_mod)
         print(json.dumps(out), flush=True)
     for b in ring:
         b.close()

@@ -5,7 +5,7 @@
 // chunks outside the timed bracket, so the figure is mixer-only bits/s (BASELINE.md
 // section 3.1), comparable with the GPU figure whose inputs are resident in HBM.
 //
-// usage: ref_mixer_bench --n N --topo "layer:table:lr,..." [--skip i,j] --bits T [--seed S]
+// usage: ref_mixer_bench --n N --topo "layer:table:lr,..." [--skip i,j] --bits T [--seed S] [--ctx-mode 0..3 --ctx-mod K]
 // prints one JSON line.
 #include <chrono>
 #include <cstdint>
@@ -38,6 +38,8 @@ int main(int argc, char** argv) {
   int n = 256;
   std::string topo_s = "0:65536:0.005", skip_s = "1";
   uint64_t T = 1000000, seed = 0;
+  int ctx_mode = 0;
+  unsigned ctx_mod = 1;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto next = [&]() -> std::string { return (i + 1 < argc) ? argv[++i] : ""; };
@@ -46,6 +48,8 @@ int main(int argc, char** argv) {
     else if (a == "--skip") skip_s = next();
     else if (a == "--bits") T = strtoull(next().c_str(), 0, 0);
     else if (a == "--seed") seed = strtoull(next().c_str(), 0, 0);
+    else if (a == "--ctx-mode") ctx_mode = atoi(next().c_str());
+    else if (a == "--ctx-mod") ctx_mod = (unsigned)strtoul(next().c_str(), 0, 0);
     else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
   }
   ShortTermMemory stm;
@@ -70,7 +74,7 @@ int main(int argc, char** argv) {
   stm.mixer_layer1_outputs = 0;
 
   gmx_synth g;
-  gmx_synth_init(&g, seed, n, M, 0, 1, 0, 0);
+  gmx_synth_init(&g, seed, n, M, ctx_mode, ctx_mod, 0, 0);
   const uint64_t CH = 4096;
   std::vector<float> xs(CH * n);
   std::vector<uint8_t> act(CH * n);
