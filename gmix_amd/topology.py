@@ -47,3 +47,30 @@ def synth3(n_inputs=256, l0=24, l1=8, table0=1 << 16, table1=1 << 8):
     """SURVEY.md Appendix A.3's 24/8/1 synthetic bank."""
     mixers = [(0, table0, 0.005)] * l0 + [(1, table1, 0.003)] * l1 + [(2, 1, 0.0005)]
     return Topology(n_inputs, mixers, skip=(1,))
+
+
+# The 41 Indirect models of the reference in construction order (predictor.cpp:78-120 AddIndirect,
+# :122-185 AddSkip, :210-250 AddDoubleIndirect): (context variable, table_size, learning_rate).
+# Each owns 256*table_size+1 one-byte states twice over and produces two of the mixers' 90 inputs.
+STOCK_INDIRECT = (
+    [("last_byte", 1 << 8, 0.02), ("last_two_bytes_hash", 1 << 16, 0.02),
+     ("last_three_bytes_hash", 1 << 15, 0.02), ("last_three_bytes_hash", 1 << 16, 0.02),
+     ("last_four_bytes_hash", 1 << 15, 0.02), ("last_five_bytes_hash", 1 << 15, 0.02),
+     ("last_six_bytes_hash", 1 << 15, 0.02)] +
+    [(f"recent_bytes[{i}]", 1 << 8, 0.02) for i in range(1, 10)] +
+    [("lstm_prediction_context", 1 << 8, 0.02)] +
+    [(c, 1 << 16, 0.02) for c in ("skip_1_2", "skip_1_2_3", "skip_0_2", "skip_0_2_3", "skip_1_2_3_4", "skip_0_3",
+                                  "skip_0_4", "skip_0_5", "skip_0_2_3_4", "skip_0_3_4", "skip_0_6", "skip_0_7",
+                                  "skip_0_1_3_4", "skip_0_4_5", "skip_0_1_2_4")] +
+    [("indirect_1_8_1", 1 << 8, 1.0 / 200), ("indirect_1_8_2", 1 << 16, 1.0 / 200),
+     ("indirect_1_8_3", 1 << 15, 1.0 / 200), ("indirect_2_16_1", 1 << 8, 1.0 / 200),
+     ("indirect_2_16_2", 1 << 16, 1.0 / 200), ("indirect_2_16_3", 1 << 15, 1.0 / 200),
+     ("indirect_3_24_1", 1 << 8, 1.0 / 200), ("indirect_4_24_2", 1 << 16, 1.0 / 200),
+     ("indirect_4_24_3", 1 << 15, 1.0 / 200)])
+
+
+def stock_indirect():
+    """[(table_size, learning_rate)] of the 41 stock Indirect models (learning rates as the float
+    the reference's constructor receives)."""
+    import numpy as np
+    return [(t, float(np.float32(lr))) for _, t, lr in STOCK_INDIRECT]

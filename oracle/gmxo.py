@@ -26,7 +26,7 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(_HERE, "libgmxoracle.so")
-        src = [os.path.join(_HERE, f) for f in ("gmx_oracle.c", "gmx_synth.h")]
+        src = [os.path.join(_HERE, f) for f in ("gmx_oracle.c", "gmx_oracle_ind.c", "gmx_synth.h", "gmx_ind_synth.h")]
         if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in src):
             subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
         L = C.CDLL(path)
@@ -210,3 +210,115 @@ def read_dump(path):
     return dict(n=n, m=m, l0=l0, l1=l1, has_final=has_final, n_skip=n_skip, T=T, dump=dump,
                 outs=rec[:, :m].copy(), p=rec[:, m].copy(), h32=h32, acc=acc, h64=h64,
                 short=short, long=long_, mem=mem)
+
+
+# ---- Indirect models (oracle/gmx_oracle_ind.c) -------------------
+def _ind_lib():
+    L = lib()
+    if not getattr(L, "_ind_ready", False):
+        L.gmxo_ind_create.restype = C.c_void_p
+        L.gmxo_ind_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gmxo_ind_destroy.argtypes = [C.c_void_p]
+        L.gmxo_ind_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.gmxo_ind_learn.argtypes = [C.c_void_p, C.c_int]
+        L.gmxo_ind_run.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                   C.c_void_p, C.c_void_p]
+        L.gmxo_ind_memory_usage.restype = C.c_uint64
+        L.gmxo_ind_memory_usage.argtypes = [C.c_void_p, C.c_int]
+        L.gmxo_ind_export.restype = C.c_size_t
+        L.gmxo_ind_export.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.gmxo_ind_synth_fill.argtypes = [C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
+        L.gmxo_ind_fnv64.restype = C.c_uint64
+        L.gmxo_ind_fnv64.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+        L._ind_ready = True
+    return L
+
+
+def ind_synth(k, T, seed=0, ctx_mod=(0, 0, 0, 0)):
+    """(ctx[T,k] u32, bit_context[T] u32, bits[T] u8) of oracle/gmx_ind_synth.h."""
+    L = _ind_lib()
+    ctx = np.zeros((T, k), np.uint32)
+    bc = np.zeros(T, np.uint32)
+    bits = np.zeros(T, np.uint8)
+    mod = np.asarray(ctx_mod, np.uint32)
+    L.gmxo_ind_synth_fill(seed, k, _p(mod), T, _p(ctx), _p(bc), _p(bits))
+    return ctx, bc, bits
+
+
+class IndirectBank:
+    """K reference Indirect models: models = [(table_size, learning_rate), ...]."""
+
+    def __init__(self, models, ns_next, rm_next):
+        self.L = _ind_lib()
+        self.k = len(models)
+        ts = np.asarray([m[0] for m in models], np.uint32)
+        lr = np.asarray([m[1] for m in models], np.float32)
+        self._ns = np.ascontiguousarray(ns_next, np.uint8).reshape(512)
+        self._rm = np.ascontiguousarray(rm_next, np.uint8).reshape(512)
+        self.h = self.L.gmxo_ind_create(self.k, _p(ts), _p(lr), _p(self._ns), _p(self._rm))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.gmxo_ind_destroy(self.h)
+            self.h = None
+
+    def predict(self, ctx, bit_context):
+        c = np.ascontiguousarray(ctx, np.uint32)
+        pred = np.zeros(2 * self.k, np.float32)
+        act = np.zeros(2 * self.k, np.uint8)
+        self.L.gmxo_ind_predict(self.h, _p(c), int(bit_context), _p(pred), _p(act))
+        return pred, act
+
+    def learn(self, bit):
+        self.L.gmxo_ind_learn(self.h, int(bit))
+
+    def run(self, ctx, bit_context, bits, nolearn_from=None):
+        T = len(bits)
+        c = np.ascontiguousarray(ctx, np.uint32)
+        bc = np.ascontiguousarray(bit_context, np.uint32)
+        b = np.ascontiguousarray(bits, np.uint8)
+        pred = np.zeros((T, 2 * self.k), np.float32)
+        act = np.zeros((T, 2 * self.k), np.uint8)
+        nl = (1 << 64) - 1 if nolearn_from is None else nolearn_from
+        self.L.gmxo_ind_run(self.h, T, _p(c), _p(bc), _p(b), nl, _p(pred), _p(act))
+        return pred, act
+
+    def memory_usage(self, i):
+        return int(self.L.gmxo_ind_memory_usage(self.h, i))
+
+    def export(self):
+        n = self.L.gmxo_ind_export(self.h, None, 0)
+        buf = np.zeros(n, np.uint8)
+        self.L.gmxo_ind_export(self.h, _p(buf), n)
+        return buf.tobytes()
+
+
+def ind_fnv64(pred, active, h0=0xcbf29ce484222325):
+    """The harness' running checksum over (prediction bits, active flag) of every slot and bit."""
+    L = _ind_lib()
+    u = np.ascontiguousarray(pred, np.float32).reshape(-1)
+    a = np.ascontiguousarray(active, np.uint8).reshape(-1)
+    return int(L.gmxo_ind_fnv64(_p(u), _p(a), len(u), h0))
+
+
+def read_ind_dump(path):
+    """GMXI file of oracle/ref_build/ref_indirect_harness."""
+    raw = open(path, "rb").read()
+    magic, K, T, D = struct.unpack_from("<4I", raw, 0)
+    assert magic == 0x49584D47
+    o = 16
+    ns_next = np.frombuffer(raw, np.uint8, 512, o).copy(); o += 512
+    rm_next = np.frombuffer(raw, np.uint8, 512, o).copy(); o += 512
+    pred = np.zeros((D, 2 * K), np.float32)
+    act = np.zeros((D, 2 * K), np.uint8)
+    for t in range(D):
+        pred[t] = np.frombuffer(raw, np.float32, 2 * K, o); o += 8 * K
+        act[t] = np.frombuffer(raw, np.uint8, 2 * K, o); o += 2 * K
+    (h64,) = struct.unpack_from("<Q", raw, o); o += 8
+    usage = np.frombuffer(raw, np.uint64, K, o).copy(); o += 8 * K
+    (ll,) = struct.unpack_from("<Q", raw, o); o += 8
+    long_b = raw[o:o + ll]
+    assert o + ll == len(raw)
+    return dict(K=K, T=T, D=D, ns_next=ns_next, rm_next=rm_next, pred=pred, active=act, h64=h64,
+                usage=usage, long=long_b)

@@ -33,3 +33,20 @@ CASES = {
     "stock90_nolearn_tail": (lambda: _t("stock", 90), 1200, 1200,
                              dict(ctx_mode=3, ctx_mod=9, bit_mode=1, nolearn_from=800)),
 }
+
+
+# Indirect models, through oracle/_ref/ref_indirect_harness:
+# name -> (models [(table_size, lr)], T bits, bits fully dumped, kwargs of gmx_ind_synth.h)
+IND_CASES = {
+    # the 41 stock models; contexts from small, medium and 32-bit domains (hash wrap, collisions)
+    "ind_stock41": (topology.stock_indirect, 12000, 1500, dict(ctx_mod=(300, 0, 70000, 5))),
+    # tables so small that they fill up: the dense branch of the checkpoint format, index wrap
+    "ind_tiny_dense": (lambda: [(1, 0.02), (2, 0.005), (3, 0.1), (1, 0.5)], 30000, 2500,
+                       dict(ctx_mod=(3, 2, 5, 1), seed=77)),
+    # generation mode: Learn stops (runner-utils.cpp:199-209)
+    "ind_nolearn_tail": (lambda: [(256, 0.02), (4096, 0.005), (65536, 0.02)], 4000, 4000,
+                         dict(ctx_mod=(40, 900, 0, 40), seed=5, nolearn_from=3000)),
+    # long run, checksum only
+    "ind_long": (lambda: [(256, 0.02), (65536, 0.02), (32768, 0.005), (256, 0.005), (65536, 0.02), (1, 0.02)],
+                 1_000_000, 0, dict(ctx_mod=(50, 0, 3000, 7), seed=99)),
+}

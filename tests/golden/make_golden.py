@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(HERE))
 
-from golden.cases import CASES  # noqa: E402
+from golden.cases import CASES, IND_CASES  # noqa: E402
 from oracle import gmxo  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref")
@@ -60,6 +60,37 @@ def run_case(name):
         outs=d["outs"].view(np.uint32), p=d["p"].view(np.uint32), mem=d["mem"],
         long=np.frombuffer(long_b if len(long_b) <= LONG_INLINE_LIMIT else b"", np.uint8))
     print(f"{name}: T={T} dump={dump} h64={d['h64']:016x} long={len(long_b)}B")
+
+
+def run_ind_case(name):
+    mk, T, dump, kw = IND_CASES[name]
+    models = mk()
+    kw = dict(kw)
+    args = [os.path.join(REF, "ref_indirect_harness"), "--models", ",".join(f"{t}:{lr!r}" for t, lr in models),
+            "--bits", str(T), "--dump", str(dump), "--ctx-mod", ",".join(map(str, kw.get("ctx_mod", (0, 0, 0, 0))))]
+    if "seed" in kw:
+        args += ["--seed", str(kw["seed"])]
+    if "nolearn_from" in kw:
+        args += ["--nolearn-from", str(kw["nolearn_from"])]
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "d.bin")
+        subprocess.run(args + ["--out", out], check=True, stdout=subprocess.DEVNULL)
+        d = gmxo.read_ind_dump(out)
+    # the indirect section is the head of the reference's .long file; its length follows from
+    # the format (long-term-memory.cpp:8-32), the rest belongs to sections that are empty here
+    ob = gmxo.IndirectBank(models, d["ns_next"], d["rm_next"])
+    n_ind = len(d["long"]) - 8
+    ind_b = d["long"][:n_ind]
+    meta = dict(name=name, models=models, T=T, dump=dump, synth=kw, h64=int(d["h64"]),
+                usage=[int(u) for u in d["usage"]], long_len=len(ind_b),
+                long_sha256=hashlib.sha256(ind_b).hexdigest(),
+                source="oracle/_ref/ref_indirect_harness (reference Indirect, g++ -O2 strict)")
+    del ob
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"), meta=json.dumps(meta), ns_next=d["ns_next"], rm_next=d["rm_next"],
+        pred=d["pred"].view(np.uint32), active=np.packbits(d["active"], axis=1, bitorder="little"),
+        long=np.frombuffer(ind_b if len(ind_b) <= LONG_INLINE_LIMIT else b"", np.uint8))
+    print(f"{name}: K={len(models)} T={T} dump={dump} h64={d['h64']:016x} long={len(ind_b)}B")
 
 
 def run_trace(n_bytes=300):
@@ -115,9 +146,11 @@ def run_trace(n_bytes=300):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + ["trace"])
+    names = sys.argv[1:] or (list(CASES) + list(IND_CASES) + ["trace"])
     for nm in names:
         if nm == "trace":
             run_trace()
+        elif nm in IND_CASES:
+            run_ind_case(nm)
         else:
             run_case(nm)

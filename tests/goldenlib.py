@@ -36,3 +36,15 @@ def unpack_trace(z, meta):
     act = np.unpackbits(z["act"], axis=1, bitorder="little")[:, :n]
     bits = np.unpackbits(z["bits"], bitorder="little")[:T]
     return pred, act, z["ctx"], bits, z["outs"], z["p"]
+
+
+def ind_case(name):
+    """(meta, models, ctx, bit_context, bits, nolearn_from, z) of an Indirect fixture; the inputs
+    are re-derived from the seed (oracle/gmx_ind_synth.h)."""
+    from oracle import gmxo
+    meta, z = load(name)
+    models = [tuple(m) for m in meta["models"]]
+    kw = dict(meta["synth"])
+    nolearn = kw.pop("nolearn_from", None)
+    ctx, bc, bits = gmxo.ind_synth(len(models), meta["T"], seed=kw.get("seed", 0), ctx_mod=kw.get("ctx_mod", (0,) * 4))
+    return meta, models, ctx, bc, bits, nolearn, z
