@@ -4,6 +4,7 @@ Mixer / Predictor surface for that path.  Nothing here computes on the CPU."""
 from . import topology
 from ._lib import ABI_SYMBOLS, LIB_PATH, GmxError, build
 from .bank import Batch, MixerGroup, Topology, device_count
+from .indirect import IndirectBatch, IndirectGroup
 
 __all__ = ["topology", "ABI_SYMBOLS", "LIB_PATH", "GmxError", "build", "Batch", "MixerGroup",
-           "Topology", "device_count"]
+           "Topology", "device_count", "IndirectGroup", "IndirectBatch"]

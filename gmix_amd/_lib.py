@@ -23,6 +23,11 @@ class MixerDesc(C.Structure):
     _fields_ = [("layer", C.c_int32), ("table_size", C.c_uint32), ("learning_rate", C.c_float)]
 
 
+class IndirectDesc(C.Structure):
+    _fields_ = [("table_size", C.c_uint32), ("learning_rate", C.c_float), ("slot_indirect", C.c_int32),
+                ("slot_run_map", C.c_int32)]
+
+
 class TopologyStruct(C.Structure):
     _fields_ = [("n_inputs", C.c_int32), ("n_skip", C.c_int32), ("skip_index", C.POINTER(C.c_int32)),
                 ("n_mixers", C.c_int32), ("mixers", C.POINTER(MixerDesc))]
@@ -82,6 +87,34 @@ def lib():
     L.gmx_bank_import.argtypes = [vp, i32, vp, C.c_size_t, vp, C.c_size_t]
     L.gmx_bank_copy.argtypes = [vp, i32, vp, i32]
     L.gmx_bank_memory_usage.argtypes = [vp, i32, i32, C.POINTER(u64)]
+    L.gmx_indirect_create.argtypes = [C.POINTER(vp), C.POINTER(IndirectDesc), i32, vp, vp, i32, i32]
+    L.gmx_indirect_destroy.argtypes = [vp]
+    L.gmx_indirect_destroy.restype = None
+    for f in (L.gmx_indirect_n_streams, L.gmx_indirect_n_models, L.gmx_indirect_reset, L.gmx_indirect_sync):
+        f.argtypes = [vp]
+    L.gmx_indirect_bank_bytes.argtypes = [vp]
+    L.gmx_indirect_bank_bytes.restype = u64
+    L.gmx_indirect_forward.argtypes = [vp, i32, vp, u32, vp, vp]
+    L.gmx_indirect_learn.argtypes = [vp, i32, i32]
+    L.gmx_ind_batch_create.argtypes = [C.POINTER(vp), vp, u64]
+    L.gmx_ind_batch_destroy.argtypes = [vp]
+    L.gmx_ind_batch_destroy.restype = None
+    L.gmx_ind_batch_max_bits.argtypes = [vp]
+    L.gmx_ind_batch_max_bits.restype = u64
+    for name in ("gmx_ind_batch_contexts", "gmx_ind_batch_bit_contexts", "gmx_ind_batch_bits",
+                 "gmx_ind_batch_predictions", "gmx_ind_batch_active"):
+        f = getattr(L, name)
+        f.argtypes = [vp]
+        f.restype = vp
+    L.gmx_ind_batch_upload.argtypes = [vp, u64]
+    L.gmx_ind_batch_download.argtypes = [vp, u64]
+    L.gmx_ind_batch_wait.argtypes = [vp]
+    L.gmx_ind_batch_fill_synthetic.argtypes = [vp, u64, u64, u64, vp]
+    L.gmx_indirect_run.argtypes = [vp, vp, u64, i32, vp, C.POINTER(C.c_float)]
+    L.gmx_indirect_export.argtypes = [vp, i32, vp, C.POINTER(C.c_size_t)]
+    L.gmx_indirect_import.argtypes = [vp, i32, vp, C.c_size_t]
+    L.gmx_indirect_copy.argtypes = [vp, i32, vp, i32]
+    L.gmx_indirect_memory_usage.argtypes = [vp, i32, C.POINTER(u64)]
     L.gmx_debug_math_probe.argtypes = [i32, vp, vp, u64, i32]
     L.gmx_debug_math_range.argtypes = [i32, u64, u64, i32, C.POINTER(C.c_ulonglong)]
     _LIB = L
@@ -103,4 +136,11 @@ ABI_SYMBOLS = [
     "gmx_batch_bits", "gmx_batch_p", "gmx_batch_outputs", "gmx_batch_upload", "gmx_batch_download",
     "gmx_batch_wait", "gmx_batch_fill_synthetic", "gmx_group_run", "gmx_bank_export",
     "gmx_bank_import", "gmx_bank_copy", "gmx_bank_memory_usage",
+    "gmx_indirect_create", "gmx_indirect_destroy", "gmx_indirect_n_streams", "gmx_indirect_n_models",
+    "gmx_indirect_bank_bytes", "gmx_indirect_reset", "gmx_indirect_sync", "gmx_indirect_forward",
+    "gmx_indirect_learn", "gmx_ind_batch_create", "gmx_ind_batch_destroy", "gmx_ind_batch_max_bits",
+    "gmx_ind_batch_contexts", "gmx_ind_batch_bit_contexts", "gmx_ind_batch_bits",
+    "gmx_ind_batch_predictions", "gmx_ind_batch_active", "gmx_ind_batch_upload", "gmx_ind_batch_download",
+    "gmx_ind_batch_wait", "gmx_ind_batch_fill_synthetic", "gmx_indirect_run", "gmx_indirect_export",
+    "gmx_indirect_import", "gmx_indirect_copy", "gmx_indirect_memory_usage",
 ]

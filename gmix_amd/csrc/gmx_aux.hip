@@ -100,6 +100,67 @@ extern "C" hipError_t gmx_launch_synth_kernel(const GmxSynthArgs* args, hipStrea
 }
 
 // ---------------------------------------------------------------------------------------
+// Synthetic records for the Indirect models (definition in oracle/gmx_ind_synth.h, restated
+// here for the device): byte-structured contexts, one thread per stream.
+// ---------------------------------------------------------------------------------------
+struct GmxIndSynthArgs {
+  uint32_t* ctx;      // [S][rec_stride][k]
+  uint32_t* bc;       // [S][rec_stride]
+  uint8_t* bits;      // [S][rec_stride]
+  uint64_t* rng;      // [S]
+  uint32_t* recent;   // [S] recent_bits
+  uint32_t* cstate;   // [S][k] contexts of the current byte
+  uint64_t rec_stride, n_bits, seed;
+  int32_t k, n_streams, restart;
+  uint32_t ctx_mod[4];
+};
+
+__global__ void __launch_bounds__(64) gmx_ind_synth_kernel(const GmxIndSynthArgs a) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.n_streams) return;
+  uint32_t* cst = a.cstate + (uint64_t)s * a.k;
+  uint64_t st;
+  uint32_t recent;
+  if (a.restart) {
+    st = a.seed + (uint64_t)s * 0x9E3779B97F4A7C15ull;
+    if (st == 0) st = 0x9E3779B97F4A7C15ull;
+    recent = 1;
+    for (int j = 0; j < a.k; ++j) cst[j] = 0u;
+  } else {
+    st = a.rng[s];
+    recent = a.recent[s];
+  }
+  for (uint64_t t = 0; t < a.n_bits; ++t) {
+    uint32_t* cx = a.ctx + ((uint64_t)s * a.rec_stride + t) * a.k;
+    if (recent == 1) {  // byte boundary: every context is redrawn
+      for (int j = 0; j < a.k; ++j) {
+        uint32_t c = gmx_xs64(st);
+        const uint32_t m = a.ctx_mod[j & 3];
+        if (m) c %= m;
+        cst[j] = c;
+      }
+    }
+    for (int j = 0; j < a.k; ++j) cx[j] = cst[j];
+    const uint32_t bcx = recent - 1;
+    a.bc[(uint64_t)s * a.rec_stride + t] = bcx;
+    const uint32_t r = gmx_xs64(st);
+    const uint32_t bit = ((cst[0] ^ (bcx * 7u)) & 1u) ^ (uint32_t)((r % 5u) == 0);
+    a.bits[(uint64_t)s * a.rec_stride + t] = (uint8_t)bit;
+    recent = recent * 2 + bit;
+    if (recent >= 256) recent = 1;
+  }
+  a.rng[s] = st;
+  a.recent[s] = recent;
+}
+
+extern "C" hipError_t gmx_launch_ind_synth_kernel(const GmxIndSynthArgs* args, hipStream_t stream) {
+  const int blocks = (args->n_streams + 63) / 64;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gmx_ind_synth_kernel, dim3(blocks), dim3(64), 0, stream, *args);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 // Device-side math probes for the parity tests (the same gmx_math.h the kernels use).
 // ---------------------------------------------------------------------------------------
 __global__ void gmx_math_probe_kernel(const float* x, float* y, uint64_t n, int what) {

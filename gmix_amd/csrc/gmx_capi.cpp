@@ -898,6 +898,8 @@ extern "C" int gmx_bank_memory_usage(gmx_group* g, int stream, int mixer, uint64
   return GMX_OK;
 }
 
+#include "gmx_indirect.inc"
+
 // ---- test probes (device math against host math; not part of the product surface) --------
 extern "C" int gmx_debug_single_variant(gmx_group* g, int lanes_per_stream) {
   if (!g || (lanes_per_stream != 0 && lanes_per_stream != 16 && lanes_per_stream != 32 &&

@@ -91,4 +91,44 @@ struct GmxMailbox {
   float outs[48];          // FORWARD result: the 33 mixer outputs
 };
 
+// ---- Indirect models (models/indirect.cpp) -------------------
+#define GMX_IND_MAX_MODELS 64
+
+struct GmxIndModelDev {
+  uint32_t size;        // 256 * table_size + 1 entries (indirect.cpp:15-19)
+  float lr;             // learning_rate_
+  int32_t slot_a;       // prediction index of "<name>-indirect" on the blackboard
+  int32_t slot_b;       // prediction index of "<name>-run_map"
+  uint64_t tab_off;     // byte offset of the model's u16 table inside a bank:
+                        // low byte = nonstationary state (255 = never seen), high byte = run-map state
+};
+
+struct GmxIndDev {
+  int32_t k, n_slots;   // models; highest slot index + 1
+  uint64_t pred_off;    // float[k][512]: per model nonstationary_predictions then run_map_predictions
+  uint64_t slots_off;   // float[2k]: what the two blackboard slots of each model hold (stale when silent)
+  uint64_t bank_bytes;
+  uint8_t ns_next[512]; // ShortTermMemory::nonstationary as a table: [state][bit]
+  uint8_t rm_next[512]; // ShortTermMemory::run_map
+  GmxIndModelDev m[GMX_IND_MAX_MODELS];
+};
+
+struct GmxIndRunArgs {
+  uint8_t* banks;
+  const uint32_t* ctx;     // [S][*][k]
+  const uint32_t* bc;      // [S][*]  bit_context
+  const uint8_t* bits;     // [S][*]
+  float* pred_out;         // [S][*][2k] or null
+  uint8_t* act_out;        // [S][*][2k] or null
+  uint64_t rec_stride, T;
+  uint32_t learn;
+  int32_t stream_base, rec_base;
+  // optional: also write into the record arrays of a mixer batch (same streams, same bits)
+  float* mx_pred;          // [S][*][mx_n_pad] or null
+  uint32_t* mx_mask;       // [S][*][mx_mask_words]
+  uint8_t* mx_bits;        // [S][*]
+  uint64_t mx_rec_stride;
+  int32_t mx_n_pad, mx_mask_words;
+};
+
 #endif  // GMX_INTERNAL_H_

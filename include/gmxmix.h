@@ -157,6 +157,83 @@ int gmx_bank_copy(gmx_group* dst, int dst_stream, gmx_group* src, int src_stream
 /* Mixer::GetMemoryUsage (mixer.cpp:197-205). */
 int gmx_bank_memory_usage(gmx_group* g, int stream, int mixer, uint64_t* bytes);
 
+/* ==== Indirect models =========================================
+ * The producers of 82 of the mixers' 90 inputs: the reference's 41 `Indirect` objects
+ * (models/indirect.h:11-34, constructed in predictor.cpp:78-120, :122-185, :210-250) and their
+ * IndirectMemory (long-term-memory.h:11-25), for S streams on one device.  With a mixer batch
+ * attached to gmx_indirect_run the predictions go from the models to the mixers inside HBM. */
+
+/* One Indirect constructor call: table_size and learning_rate as in indirect.h:16-18; the two
+ * prediction indices ShortTermMemory::AddPrediction returned for "<description>-indirect" and
+ * "<description>-run_map" (indirect.cpp:10-13). */
+typedef struct gmx_indirect_desc {
+  uint32_t table_size;       /* the model owns 256 * table_size + 1 states (indirect.cpp:14-19) */
+  float learning_rate;
+  int32_t slot_indirect;
+  int32_t slot_run_map;
+} gmx_indirect_desc;
+
+typedef struct gmx_indirect gmx_indirect;
+typedef struct gmx_ind_batch gmx_ind_batch;
+
+/* nonstationary_next / run_map_next: [256][2] next-state tables, state-major, of the two state
+ * machines ShortTermMemory owns (short-term-memory.h `nonstationary`, `run_map`; the models call
+ * their Next(state, bit), indirect.cpp:61-62, :67-68): fill them by calling Next() 512 times. */
+int gmx_indirect_create(gmx_indirect** out, const gmx_indirect_desc* models, int n_models,
+                        const uint8_t* nonstationary_next, const uint8_t* run_map_next,
+                        int n_streams, int device);
+void gmx_indirect_destroy(gmx_indirect* ib);
+int gmx_indirect_n_streams(const gmx_indirect* ib);
+int gmx_indirect_n_models(const gmx_indirect* ib);
+uint64_t gmx_indirect_bank_bytes(const gmx_indirect* ib);   /* device bytes per stream */
+int gmx_indirect_reset(gmx_indirect* ib);                   /* every table back to "never seen" */
+int gmx_indirect_sync(gmx_indirect* ib);
+
+/* Per-bit surface.  forward = n_models x Indirect::Predict (indirect.cpp:28-46): contexts[i] is
+ * the value of model i's aliased context variable now, bit_context is
+ * ShortTermMemory::bit_context; predictions[2*n_models] / active[2*n_models] (nullable) receive
+ * what the blackboard slots of model i hold afterwards ([2i] indirect, [2i+1] run map: a model
+ * that stays silent leaves its slot as it was) and whether SetLogitPrediction marked them
+ * active (short-term-memory.cpp:193-197).  learn = n_models x Indirect::Learn
+ * (indirect.cpp:48-69) with the contexts of the preceding forward. */
+int gmx_indirect_forward(gmx_indirect* ib, int stream, const uint32_t* contexts, uint32_t bit_context,
+                         float* predictions, uint8_t* active);
+int gmx_indirect_learn(gmx_indirect* ib, int stream, int bit);
+
+/* Batched surface: records {contexts[n_models], bit_context, bit} of up to max_bits bits per
+ * stream, results {predictions[2*n_models], active[2*n_models]} per bit. */
+int gmx_ind_batch_create(gmx_ind_batch** out, gmx_indirect* ib, uint64_t max_bits);
+void gmx_ind_batch_destroy(gmx_ind_batch* b);
+uint64_t gmx_ind_batch_max_bits(const gmx_ind_batch* b);
+uint32_t* gmx_ind_batch_contexts(gmx_ind_batch* b);       /* pinned host [S][max_bits][n_models] */
+uint32_t* gmx_ind_batch_bit_contexts(gmx_ind_batch* b);   /* [S][max_bits] */
+uint8_t* gmx_ind_batch_bits(gmx_ind_batch* b);            /* [S][max_bits] */
+const float* gmx_ind_batch_predictions(gmx_ind_batch* b); /* [S][max_bits][2*n_models] */
+const uint8_t* gmx_ind_batch_active(gmx_ind_batch* b);    /* [S][max_bits][2*n_models] */
+int gmx_ind_batch_upload(gmx_ind_batch* b, uint64_t n_bits);
+int gmx_ind_batch_download(gmx_ind_batch* b, uint64_t n_bits);
+int gmx_ind_batch_wait(gmx_ind_batch* b);
+/* Device-side generator of the synthetic stream of oracle/gmx_ind_synth.h (byte-structured
+ * contexts, ctx_mod[4] moduli); stream s is seeded with seed + s * 0x9E3779B97F4A7C15. */
+int gmx_ind_batch_fill_synthetic(gmx_ind_batch* b, uint64_t n_bits, uint64_t seed, uint64_t restart,
+                                 const uint32_t* ctx_mod);
+/* Predict (+ Learn when learn != 0) for bits [0, n_bits) of every stream.  `into` (nullable): a
+ * batch of a mixer group with the same number of streams on the same device, created with
+ * GMX_BATCH_MASK; the models' predictions are also written into its device prediction records
+ * at their slot indices, their active bits replace those slots' bits of its mask records, and
+ * the coded bits are copied into its bit records -- ordered after what was queued on the mixer
+ * group before this call and before what is queued on it afterwards. */
+int gmx_indirect_run(gmx_indirect* ib, gmx_ind_batch* b, uint64_t n_bits, int learn, gmx_batch* into,
+                     float* kernel_ms);
+
+/* The indirect section of LongTermMemory::WriteToDisk / ReadFromDisk (long-term-memory.cpp:8-32,
+ * :111-132), byte for byte; NULL buf to size.  Copy = long-term-memory.cpp:193-199;
+ * memory_usage = Indirect::GetMemoryUsage (indirect.cpp:71-78). */
+int gmx_indirect_export(gmx_indirect* ib, int stream, void* buf, size_t* bytes);
+int gmx_indirect_import(gmx_indirect* ib, int stream, const void* buf, size_t bytes);
+int gmx_indirect_copy(gmx_indirect* dst, int dst_stream, gmx_indirect* src, int src_stream);
+int gmx_indirect_memory_usage(gmx_indirect* ib, int model, uint64_t* bytes);
+
 #ifdef __cplusplus
 }
 #endif

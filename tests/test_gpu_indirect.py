@@ -1,0 +1,176 @@
+"""The Indirect-model banks (gmx_indirect.hip behind gmx_indirect_* of include/gmxmix.h) against
+the golden vectors of the REAL reference class and against the oracle: every prediction slot and
+active flag, the checkpoint bytes, per-bit vs batched, and the models feeding a mixer batch
+inside HBM."""
+import numpy as np
+import pytest
+
+import goldenlib
+from gmix_amd import topology
+from golden.cases import IND_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+def u32(x):
+    return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+def run_batched(gpu, models, tabs, streams, chunk, nolearn_from=None):
+    """streams: [(ctx, bc, bits)]; returns (group, pred[S,T,2K], act[S,T,2K])."""
+    S, T, K = len(streams), len(streams[0][2]), len(models)
+    g = gpu.IndirectGroup(models, tabs[0], tabs[1], S)
+    b = gpu.IndirectBatch(g, chunk)
+    P = np.zeros((S, T, 2 * K), np.float32)
+    A = np.zeros((S, T, 2 * K), np.uint8)
+    t0 = 0
+    while t0 < T:
+        n = min(chunk, T - t0)
+        learn = True
+        if nolearn_from is not None:
+            if t0 < nolearn_from:
+                n = min(n, nolearn_from - t0)
+            else:
+                learn = False
+        for s, (ctx, bc, bits) in enumerate(streams):
+            b.set_records(s, ctx[t0:t0 + n], bc[t0:t0 + n], bits[t0:t0 + n])
+        b.upload(n)
+        g.run(b, n, learn=learn)
+        b.download(n)
+        b.wait()
+        P[:, t0:t0 + n] = b.predictions[:, :n]
+        A[:, t0:t0 + n] = b.active[:, :n]
+        t0 += n
+    b.close()
+    return g, P, A
+
+
+@pytest.mark.parametrize("name", sorted(IND_CASES))
+def test_indirect_kernel_matches_reference_goldens(gpu, oracle, name):
+    meta, models, ctx, bc, bits, nolearn, z = goldenlib.ind_case(name)
+    T = meta["T"]
+    chunk = 4096 if T > 50000 else 1000
+    g, P, A = run_batched(gpu, models, (z["ns_next"], z["rm_next"]), [(ctx, bc, bits)], chunk, nolearn)
+    D, K = meta["dump"], len(models)
+    if D:
+        assert np.array_equal(u32(P[0, :D]), z["pred"])
+        assert np.array_equal(A[0, :D], np.unpackbits(z["active"], axis=1, bitorder="little")[:, :2 * K])
+    assert oracle.ind_fnv64(P[0], A[0]) == meta["h64"]
+    e = g.export(0)
+    assert len(e) == meta["long_len"] and goldenlib.sha256(e) == meta["long_sha256"]
+    assert [g.memory_usage(i) for i in range(K)] == meta["usage"]
+    g.close()
+
+
+def test_indirect_streams_are_independent_and_per_bit_agrees(gpu, oracle):
+    _, z = goldenlib.load("ind_tiny_dense")
+    tabs = (z["ns_next"], z["rm_next"])
+    models = [(256, 0.02), (3, 0.1), (4096, 0.005), (1, 0.5), (65536, 0.02)]
+    S, T = 4, 1500
+    streams = [oracle.ind_synth(len(models), T, seed=11 + s, ctx_mod=(40, 3, 900, 0)) for s in range(S)]
+    g, P, A = run_batched(gpu, models, tabs, streams, 700)
+    refs = []
+    for s in range(S):
+        ob = oracle.IndirectBank(models, *tabs)
+        p, a = ob.run(*streams[s])
+        assert np.array_equal(u32(P[s]), u32(p)) and np.array_equal(A[s], a), s
+        assert g.export(s) == ob.export()
+        refs.append(ob)
+    # continue stream 1 one bit at a time (Predict / Learn), stream 2 untouched
+    ctx, bc, bits = oracle.ind_synth(len(models), 300, seed=99, ctx_mod=(40, 3, 900, 0))
+    for t in range(300):
+        p, a = g.forward(ctx[t], bc[t], stream=1)
+        pr, ar = refs[1].predict(ctx[t], bc[t])
+        assert np.array_equal(u32(p), u32(pr)) and np.array_equal(a, ar), t
+        if t % 7 != 3:                       # a Predict without Learn now and then (generation)
+            g.learn(bits[t], stream=1)
+            refs[1].learn(bits[t])
+    assert g.export(1) == refs[1].export() and g.export(2) == refs[2].export()
+    with pytest.raises(gpu.GmxError):
+        g.learn(1, stream=2)                 # Learn without Predict
+    # checkpoint round trip and copy
+    g2 = gpu.IndirectGroup(models, *tabs, 2)
+    g2.import_(g.export(1), stream=0)
+    g2.copy_from(g, src_stream=3, dst_stream=1)
+    assert g2.export(0) == g.export(1) and g2.export(1) == g.export(3)
+    with pytest.raises(gpu.GmxError):
+        g2.import_(g.export(1)[:-5], stream=0)
+    g.close()
+    g2.close()
+
+
+def test_indirect_models_feed_the_mixers_inside_hbm(gpu, oracle):
+    """41 stock Indirect models -> 82 of the 90 mixer inputs, written by gmx_indirect_run straight
+    into the mixer batch's device records; the other 8 inputs, the mixer contexts come from the
+    host.  The mixer outputs must equal the oracle chain Indirect -> Mixer."""
+    _, z = goldenlib.load("ind_stock41")
+    tabs = (z["ns_next"], z["rm_next"])
+    models = topology.stock_indirect()
+    K, N, T, S = len(models), 90, 1200, 2
+    topo = topology.stock(90)
+    # blackboard layout as in the reference's constructor order: 8 other predictions first
+    # (slots 0..7: PPMd, LSTM, matches), then the Indirect pairs
+    slots = [(8 + 2 * i, 9 + 2 * i) for i in range(K)]
+    ig = gpu.IndirectGroup(models, *tabs, S, slots=slots)
+    mg = gpu.MixerGroup(topo, S)
+    ib = gpu.IndirectBatch(ig, T)
+    mb = gpu.Batch(mg, T, outputs=True, mask=True)
+    want = []
+    for s in range(S):
+        ctx, bc, bits = oracle.ind_synth(K, T, seed=500 + s, ctx_mod=(300, 0, 70000, 5))
+        other, act_o, mctx, _ = oracle.synth(N, 33, T, seed=900 + s, ctx_mode=2, zero_mod=4)
+        ib.set_records(s, ctx, bc, bits)
+        act_full = np.zeros((T, N), np.uint8)
+        act_full[:, :8] = act_o[:, :8]
+        mb.set_records(s, other, act_full, mctx, np.zeros(T, np.uint8))  # bits arrive from the models' batch
+        # oracle chain
+        ob = oracle.IndirectBank(models, *tabs)
+        ip, ia = ob.run(ctx, bc, bits)
+        pred = other.copy()
+        act = act_full.copy()
+        for i, (a, b_) in enumerate(slots):
+            pred[:, a], pred[:, b_] = ip[:, 2 * i], ip[:, 2 * i + 1]
+            act[:, a], act[:, b_] = ia[:, 2 * i], ia[:, 2 * i + 1]
+        om = oracle.Bank(N, topo.skip, topo.mixers)
+        want.append(om.run(pred, act, mctx, bits) + (om, ob))
+    ib.upload(T)
+    mb.upload(T)
+    ig.run(ib, T, learn=True, into=mb)
+    mg.run(mb, T, learn=True)
+    mb.download(T)
+    mb.wait()
+    for s in range(S):
+        p_ref, o_ref, om, ob = want[s]
+        assert np.array_equal(u32(mb.outputs[s, :T]), u32(o_ref)), s
+        assert np.array_equal(u32(mb.p[s, :T]), u32(p_ref))
+        assert mg.export(s) == (om.export_long(), om.export_short())
+        assert ig.export(s) == ob.export()
+    for x in (ib, mb, ig, mg):
+        x.close()
+
+
+def test_indirect_device_synth_is_the_oracles_stream(gpu, oracle):
+    _, z = goldenlib.load("ind_tiny_dense")
+    models = [(256, 0.02), (65536, 0.02), (32768, 0.005)]
+    S, T = 3, 900
+    g = gpu.IndirectGroup(models, z["ns_next"], z["rm_next"], S)
+    b = gpu.IndirectBatch(g, T)
+    b.fill_synthetic(500, seed=1234, restart=True, ctx_mod=(50, 0, 3000, 7))
+    g.run(b, 500, learn=True)
+    b.download(500)
+    b.wait()
+    first = (b.predictions[:, :500].copy(), b.active[:, :500].copy())
+    b.fill_synthetic(400, restart=False, ctx_mod=(50, 0, 3000, 7))   # the stream continues
+    g.run(b, 400, learn=True)
+    b.download(400)
+    b.wait()
+    for s in range(S):
+        ctx, bc, bits = oracle.ind_synth(len(models), T, seed=(1234 + s * 0x9E3779B97F4A7C15) % (1 << 64),
+                                         ctx_mod=(50, 0, 3000, 7))
+        ob = oracle.IndirectBank(models, z["ns_next"], z["rm_next"])
+        p, a = ob.run(ctx, bc, bits)
+        assert np.array_equal(u32(first[0][s]), u32(p[:500])) and np.array_equal(first[1][s], a[:500])
+        assert np.array_equal(u32(b.predictions[s, :400]), u32(p[500:])) and np.array_equal(b.active[s, :400], a[500:])
+        assert g.export(s) == ob.export()
+    b.close()
+    g.close()
