@@ -20,6 +20,39 @@
 #include "gmx_internal.h"
 #include "gmx_math.h"
 
+// Loads of the block pipeline are issued from inline asm: left to itself hipcc sinks them next to
+// their uses, which puts one memory latency back into every bit.
+__device__ __forceinline__ void ind_ld32(uint32_t& d, const uint32_t* p) {
+  asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void ind_ld32o(uint32_t& d, const void* p) {
+  asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(d) : "v"(p), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void ind_ld8o(uint32_t& d, const void* p) {
+  asm volatile("global_load_ubyte %0, %1, off offset:%2" : "=v"(d) : "v"(p), "n"(OFF) : "memory");
+}
+template <int J, int D>
+__device__ __forceinline__ void ind_block_records(uint32_t* ctx_n, uint32_t* bc_n, uint32_t* bit_n,
+                                                  const uint32_t* ctx_p, uint32_t k_bytes, const uint32_t* bc_p,
+                                                  const uint8_t* bit_p) {
+  if constexpr (J < D) {
+    ind_ld32(ctx_n[J], (const uint32_t*)((const uint8_t*)ctx_p + (uint64_t)J * k_bytes));
+    ind_ld32o<4 * J>(bc_n[J], bc_p);
+    ind_ld8o<J>(bit_n[J], bit_p);
+    ind_block_records<J + 1, D>(ctx_n, bc_n, bit_n, ctx_p, k_bytes, bc_p, bit_p);
+  }
+}
+__device__ __forceinline__ void ind_ld16(uint32_t& d, const uint16_t* p) {
+  asm volatile("global_load_ushort %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void ind_ld8(uint32_t& d, const uint8_t* p) {
+  asm volatile("global_load_ubyte %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+
+// OUT: write {predictions, active} records; MX: write into a mixer batch; LEARN: Indirect::Learn.
+template <bool OUT, bool MX, bool LEARN>
 __global__ void __launch_bounds__(64)
 gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -47,26 +80,29 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
   __syncthreads();
 
   const bool on = lane < K;
-  const GmxIndModelDev d = dv->m[on ? lane : 0];
+  // idle lanes mirror model 0: same values to the same addresses, so the loop needs no exec
+  // masking at all (a divergent region around the stores also makes hipcc drain vmcnt per bit)
+  const int ml = on ? lane : 0;
+  const GmxIndModelDev d = dv->m[ml];
   uint16_t* const tab = (uint16_t*)(bank + d.tab_off);
   float* const slots = (float*)(bank + dv->slots_off);
-  float va = on ? slots[2 * lane] : 0.f, vb = on ? slots[2 * lane + 1] : 0.f;
-  float* const nsp = ptab + (size_t)lane * 512;
+  float va = slots[2 * ml], vb = slots[2 * ml + 1];
+  float* const nsp = ptab + (size_t)ml * 512;
   float* const rmp = nsp + 256;
 
   const uint64_t RS = a.rec_stride;
   const uint32_t* const ctx_s = a.ctx + (uint64_t)rec * RS * K;
   const uint32_t* const bc_s = a.bc + (uint64_t)rec * RS;
   const uint8_t* const bits_s = a.bits + (uint64_t)rec * RS;
-  float* const po = a.pred_out ? a.pred_out + (uint64_t)rec * RS * 2 * K : nullptr;
-  uint8_t* const ao = a.act_out ? a.act_out + (uint64_t)rec * RS * 2 * K : nullptr;
-  float* const mxp = a.mx_pred ? a.mx_pred + (uint64_t)rec * a.mx_rec_stride * a.mx_n_pad : nullptr;
-  uint32_t* const mxm = a.mx_pred ? a.mx_mask + (uint64_t)rec * a.mx_rec_stride * a.mx_mask_words : nullptr;
-  uint8_t* const mxb = a.mx_pred ? a.mx_bits + (uint64_t)rec * a.mx_rec_stride : nullptr;
+  float* const po = OUT ? a.pred_out + (uint64_t)rec * RS * 2 * K : nullptr;
+  uint8_t* const ao = OUT ? a.act_out + (uint64_t)rec * RS * 2 * K : nullptr;
+  float* const mxp = MX ? a.mx_pred + (uint64_t)rec * a.mx_rec_stride * a.mx_n_pad : nullptr;
+  uint32_t* const mxm = MX ? a.mx_mask + (uint64_t)rec * a.mx_rec_stride * a.mx_mask_words : nullptr;
+  uint8_t* const mxb = MX ? a.mx_bits + (uint64_t)rec * a.mx_rec_stride : nullptr;
   const int MW = a.mx_mask_words;
   // bits of the attached mask that belong to the Indirect models (cleared and rewritten per bit)
   uint32_t own = 0;
-  if (mxp) {
+  if (MX) {
     if (lane < MW) mw[lane] = 0;
     __syncthreads();
     if (on) {
@@ -78,84 +114,165 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
     __syncthreads();
   }
 
-  // entry of bit 0
-  uint32_t idx = on ? (uint32_t)(((ctx_s[lane] << 8) + bc_s[0]) % d.size) : 0u;  // indirect.cpp:31-32
-  uint32_t e = on ? tab[idx] : 0x00ffu;
-  for (uint64_t t = 0; t < T; ++t) {
-    // fetch the entry of bit t+1 (its index does not depend on this bit's outcome)
-    uint32_t idx_n = 0, e_n = 0x00ffu;
-    if (on && t + 1 < T) {
-      idx_n = (uint32_t)(((ctx_s[(t + 1) * K + lane] << 8) + bc_s[t + 1]) % d.size);
-      e_n = tab[idx_n];
+  // Bits are processed in blocks of D.  The table indices of a block depend on the records only,
+  // so its D entries are fetched together -- one memory latency per block instead of one per
+  // bit -- behind the records of the next block; an entry that the block itself rewrites
+  // before using it again is patched from registers.  The body is branch-free per lane
+  // (selects): with one wave per stream every exec-mask detour costs.  (Fetching block b+1's
+  // entries during block b was tried: what it hides is less than what patching across blocks
+  // costs -- the loop is bound by its dependent LDS/logistic chain, not by the fetch.)
+  constexpr int D = 8;
+  uint32_t prev_ctx = 0, base = 0;
+  bool have_base = false;
+  // ((context << 8) + bit_context) % size (indirect.cpp:31-32, 32-bit wrap).  A model's context
+  // changes once per byte, so the residue of (context << 8) is kept.
+  auto index_of = [&](uint32_t ctx, uint32_t bcu) -> uint32_t {
+    const bool moved = !have_base || ctx != prev_ctx;
+    if (__ballot(moved)) {  // wave-uniform
+      const uint32_t nb = (ctx << 8) % d.size;
+      base = moved ? nb : base;
+      prev_ctx = ctx;
+      have_base = true;
     }
-    const int bit = bits_s[t];
-    // ---- Indirect::Predict (indirect.cpp:28-46) --------------------------------------------
-    const uint32_t ns = e & 255u, rm = e >> 8;
-    bool act_a = false, act_b = false;
-    if (on) {
-      if (ns != 255u) {
-        va = nsp[ns];
-        act_a = va != 0.f;  // SetLogitPrediction: a zero logit is stored, not active
+    if (bcu < 256u) {  // always true for the reference's bit_context
+      const uint32_t ix = base + bcu;
+      return ix >= d.size ? ix - d.size : ix;
+    }
+    return ((ctx << 8) + bcu) % d.size;
+  };
+  auto load_records = [&](uint32_t* c, uint32_t* bcv, uint32_t* bv, uint64_t t_first) {
+    if (t_first + D <= T) {
+      ind_block_records<0, D>(c, bcv, bv, ctx_s + t_first * K + ml, (uint32_t)K * 4u, bc_s + t_first,
+                              bits_s + t_first);
+    } else {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {  // the last blocks: clamped (values past T are not used)
+        uint64_t t = t_first + j;
+        t = t < T ? t : T - 1;
+        ind_ld32(c[j], ctx_s + t * K + ml);
+        ind_ld32(bcv[j], bc_s + t);
+        ind_ld8o<0>(bv[j], bits_s + t);
       }
-      if (rm != 0u) {
-        vb = rmp[rm];
-        act_b = vb != 0.f;
+    }
+  };
+  uint32_t ctx_r[D], bc_r[D], bit_r[D];
+  load_records(ctx_r, bc_r, bit_r, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < D; ++j) asm volatile("" : "+v"(ctx_r[j]), "+v"(bc_r[j]), "+v"(bit_r[j]));
+
+  for (uint64_t t0 = 0; t0 < T; t0 += D) {
+    // records of the next block first: vector memory returns in order, so once this block's
+    // entries (issued behind them) are there, nothing is left to wait for while the bits run
+    uint32_t ctx_n[D], bc_n[D], bit_n[D], idx[D], e[D];
+    load_records(ctx_n, bc_n, bit_n, t0 + D);
+    // Inside one byte (one context, bit_context growing) the D indices are distinct: the usual
+    // case, blocks being bytes.  Otherwise an entry may come twice and is patched below.
+    bool plain = true;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const uint32_t bcu = __builtin_amdgcn_readfirstlane(bc_r[j]);
+      idx[j] = index_of(ctx_r[j], bcu);
+      ind_ld16(e[j], tab + idx[j]);
+      plain = plain && bcu < 256u;
+      if (j > 0) plain = plain && ctx_r[j] == ctx_r[0] && bcu > __builtin_amdgcn_readfirstlane(bc_r[j - 1]);
+    }
+    const bool patch = __ballot(!plain) != 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < D; ++j)  // pins the loaded registers behind the wait
+      asm volatile("" : "+v"(e[j]), "+v"(ctx_n[j]), "+v"(bc_n[j]), "+v"(bit_n[j]));
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const uint64_t t = t0 + j;
+      if (t >= T) break;
+      const int bit = (int)__builtin_amdgcn_readfirstlane(bit_r[j]);
+      // ---- Indirect::Predict (indirect.cpp:28-46) ------------------------------------------
+      const uint32_t ns = e[j] & 255u, rm = e[j] >> 8;
+      const float qa = nsp[ns], qb = rmp[rm];
+      const bool seen_a = ns != 255u, seen_b = rm != 0u;  // never-seen states leave the slot alone
+      va = seen_a ? qa : va;
+      vb = seen_b ? qb : vb;
+      const bool act_a = seen_a && qa != 0.f;  // SetLogitPrediction: a zero logit is stored, not active
+      const bool act_b = seen_b && qb != 0.f;
+      if (OUT) {
+        *(float2*)(po + t * 2 * K + 2 * ml) = make_float2(va, vb);
+        *(uchar2*)(ao + t * 2 * K + 2 * ml) = make_uchar2(act_a, act_b);
       }
-      if (po) {
-        *(float2*)(po + t * 2 * K + 2 * lane) = make_float2(va, vb);
-        *(uchar2*)(ao + t * 2 * K + 2 * lane) = make_uchar2(act_a, act_b);
-      }
-      if (mxp) {
+      if (MX) {
         mxp[t * a.mx_n_pad + d.slot_a] = va;
         mxp[t * a.mx_n_pad + d.slot_b] = vb;
+        if (lane < MW) mw[lane] = 0;
+        __syncthreads();
+        if (act_a) atomicOr(&mw[d.slot_a >> 5], 1u << (d.slot_a & 31));
+        if (act_b) atomicOr(&mw[d.slot_b >> 5], 1u << (d.slot_b & 31));
+        __syncthreads();
+        if (lane < MW) {
+          uint32_t* wp = mxm + t * MW + lane;
+          *wp = (*wp & ~own) | mw[lane];
+        }
+        if (lane == 0) mxb[t] = (uint8_t)bit;
+        __syncthreads();
+      }
+      // ---- Indirect::Learn (indirect.cpp:48-69) --------------------------------------------
+      if (LEARN) {
+        const uint32_t sn = seen_a ? ns : 0u;  // the uninitialised state learns as state 0
+        const float pa = nsp[sn];
+        const float na = pa + ((float)bit - gmx_logistic_tab(pa, s_tab)) * d.lr;
+        const float nb = qb + ((float)bit - gmx_logistic_tab(qb, s_tab)) * d.lr;
+        const uint32_t e_new = (uint32_t)nsn[2 * sn + bit] | ((uint32_t)rmn[2 * rm + bit] << 8);
+        nsp[sn] = na;
+        rmp[rm] = nb;
+        tab[idx[j]] = (uint16_t)e_new;
+        if (patch) {
+#pragma unroll
+          for (int i = j + 1; i < D; ++i)  // the same entry again later in this block
+            e[i] = idx[i] == idx[j] ? e_new : e[i];
+        }
       }
     }
-    if (mxp) {
-      if (lane < MW) mw[lane] = 0;
-      __syncthreads();
-      if (act_a) atomicOr(&mw[d.slot_a >> 5], 1u << (d.slot_a & 31));
-      if (act_b) atomicOr(&mw[d.slot_b >> 5], 1u << (d.slot_b & 31));
-      __syncthreads();
-      if (lane < MW) {
-        uint32_t* w = mxm + t * MW + lane;
-        *w = (*w & ~own) | mw[lane];
-      }
-      if (lane == 0) mxb[t] = (uint8_t)bit;
-      __syncthreads();
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      ctx_r[j] = ctx_n[j];
+      bc_r[j] = bc_n[j];
+      bit_r[j] = bit_n[j];
     }
-    // ---- Indirect::Learn (indirect.cpp:48-69) ----------------------------------------------
-    if (a.learn && on) {
-      const uint32_t sn = ns == 255u ? 0u : ns;  // the uninitialised state learns as state 0
-      const float pa = nsp[sn];
-      nsp[sn] = pa + ((float)bit - gmx_logistic_tab(pa, s_tab)) * d.lr;
-      const float pb = rmp[rm];
-      rmp[rm] = pb + ((float)bit - gmx_logistic_tab(pb, s_tab)) * d.lr;
-      const uint32_t e_new = (uint32_t)nsn[2 * sn + bit] | ((uint32_t)rmn[2 * rm + bit] << 8);
-      tab[idx] = (uint16_t)e_new;
-      if (idx_n == idx && t + 1 < T) e_n = e_new;  // same entry twice in a row: take it from here
-    }
-    idx = idx_n;
-    e = e_n;
   }
-  if (on) {
-    slots[2 * lane] = va;
-    slots[2 * lane + 1] = vb;
-  }
+  slots[2 * ml] = va;
+  slots[2 * ml + 1] = vb;
   __syncthreads();
-  if (a.learn)
+  if (LEARN)
     for (int i = lane; i < K * 512; i += 64) gp[i] = ptab[i];
 }
 
-extern "C" hipError_t gmx_indirect_kernel_set_lds(unsigned lds_bytes) {
-  return hipFuncSetAttribute((const void*)gmx_indirect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)lds_bytes);
+template <bool OUT, bool MX, bool LEARN>
+static hipError_t ind_launch_as(const GmxIndDev* dv, const GmxIndRunArgs* args, int n_streams, unsigned lds_bytes,
+                                hipStream_t stream) {
+  static unsigned allowed = 48u * 1024u;  // per instantiation: dynamic LDS the runtime has been told about
+  if (lds_bytes > allowed) {
+    hipError_t e = hipFuncSetAttribute((const void*)gmx_indirect_kernel<OUT, MX, LEARN>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    allowed = lds_bytes;
+  }
+  hipLaunchKernelGGL((gmx_indirect_kernel<OUT, MX, LEARN>), dim3(n_streams), dim3(64), lds_bytes, stream, dv, *args);
+  return hipGetLastError();
 }
 
 extern "C" hipError_t gmx_launch_indirect_kernel(const GmxIndDev* dv, const GmxIndRunArgs* args, int n_streams,
                                                  unsigned lds_bytes, hipStream_t stream) {
   (void)hipGetLastError();
-  hipLaunchKernelGGL(gmx_indirect_kernel, dim3(n_streams), dim3(64), lds_bytes, stream, dv, *args);
-  return hipGetLastError();
+  const bool out = args->pred_out != nullptr, mx = args->mx_pred != nullptr, learn = args->learn != 0;
+  if (out) {
+    if (mx) return learn ? ind_launch_as<true, true, true>(dv, args, n_streams, lds_bytes, stream)
+                         : ind_launch_as<true, true, false>(dv, args, n_streams, lds_bytes, stream);
+    return learn ? ind_launch_as<true, false, true>(dv, args, n_streams, lds_bytes, stream)
+                 : ind_launch_as<true, false, false>(dv, args, n_streams, lds_bytes, stream);
+  }
+  if (mx) return learn ? ind_launch_as<false, true, true>(dv, args, n_streams, lds_bytes, stream)
+                       : ind_launch_as<false, true, false>(dv, args, n_streams, lds_bytes, stream);
+  return learn ? ind_launch_as<false, false, true>(dv, args, n_streams, lds_bytes, stream)
+               : ind_launch_as<false, false, false>(dv, args, n_streams, lds_bytes, stream);
 }
 
 // Fill every model's table with "never seen" (nonstationary 255, run map 0) and zero the rest.
