@@ -62,6 +62,8 @@ def lib():
     for f in (L.gmx_group_n_streams, L.gmx_group_n_mixers, L.gmx_group_n_inputs, L.gmx_group_reset,
               L.gmx_group_sync):
         f.argtypes = [vp]
+    L.gmx_group_timer_start.argtypes = [vp]
+    L.gmx_group_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     L.gmx_group_bank_bytes.argtypes = [vp]
     L.gmx_group_bank_bytes.restype = u64
     L.gmx_bank_forward.argtypes = [vp, i32, vp, vp, i32, vp, C.POINTER(C.c_float), vp]
@@ -130,7 +132,7 @@ def check(status, where):
 ABI_SYMBOLS = [
     "gmx_strerror", "gmx_last_error", "gmx_device_count", "gmx_build_info", "gmx_group_create",
     "gmx_group_destroy", "gmx_group_n_streams", "gmx_group_n_mixers", "gmx_group_n_inputs",
-    "gmx_group_bank_bytes", "gmx_group_reset", "gmx_group_sync", "gmx_bank_forward", "gmx_bank_learn",
+    "gmx_group_bank_bytes", "gmx_group_reset", "gmx_group_sync", "gmx_group_timer_start", "gmx_group_timer_stop", "gmx_bank_forward", "gmx_bank_learn",
     "gmx_batch_create", "gmx_batch_destroy", "gmx_batch_n_pad", "gmx_batch_mask_words",
     "gmx_batch_max_bits", "gmx_batch_predictions", "gmx_batch_active_mask", "gmx_batch_contexts",
     "gmx_batch_bits", "gmx_batch_p", "gmx_batch_outputs", "gmx_batch_upload", "gmx_batch_download",

@@ -91,6 +91,14 @@ class MixerGroup:
     def bank_bytes(self):
         return self.L.gmx_group_bank_bytes(self.h)
 
+    def timer_start(self):
+        check(self.L.gmx_group_timer_start(self.h), "gmx_group_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        check(self.L.gmx_group_timer_stop(self.h, C.byref(ms)), "gmx_group_timer_stop")
+        return ms.value
+
     # ---- per-bit surface (Predict / Perceive+Learn) ----
     def forward(self, predictions, active, contexts, stream=0, want_all=True):
         pred = np.ascontiguousarray(predictions, np.float32)

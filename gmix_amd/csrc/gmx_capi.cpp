@@ -79,12 +79,21 @@ struct gmx_group {
   unsigned lds_bytes = 0;
   std::vector<uint64_t> steps;     // host mirror of Mixer::steps_ (identical for all mixers of a stream)
   std::vector<uint8_t> fwd_done;   // per-bit protocol: forward seen, learn allowed
-  // decay tables staging
-  float* decay_dev = nullptr;
-  uint32_t* decay_idx_dev = nullptr;
-  float* decay_host = nullptr;     // pinned
-  uint32_t* decay_idx_host = nullptr;
-  size_t decay_cap = 0;            // floats
+  // decay tables: two staging slots used alternately, so the host prepares launch k+1 while
+  // launch k still reads its tables
+  struct DecaySlot {
+    float* dev = nullptr;
+    uint32_t* idx_dev = nullptr;
+    float* host = nullptr;         // pinned
+    uint32_t* idx_host = nullptr;
+    size_t cap = 0;                // floats
+    hipEvent_t done = nullptr;     // recorded behind the kernel that read this slot
+    hipEvent_t ready = nullptr;    // recorded behind the upload on copy_stream
+    bool busy = false;
+  } decay[2];
+  hipStream_t copy_stream = nullptr;  // uploads of the decay tables, beside the running kernel
+  unsigned run_seq = 0;
+  hipEvent_t tm0 = nullptr, tm1 = nullptr;  // gmx_group_timer_*
   gmx_batch* one = nullptr;        // 1-bit batch (one record per stream) of the per-bit surface
   std::vector<gmx_batch*> batches; // live batches; orphaned (b->g = nullptr) when the group dies
   std::vector<struct GmxSession*> sessions;  // per stream, lazily: persistent per-bit kernels
@@ -324,10 +333,17 @@ extern "C" void gmx_group_destroy(gmx_group* g) {
   if (g->banks) (void)hipFree(g->banks);
   if (g->latch_out) (void)hipFree(g->latch_out);
   if (g->topo_dev) (void)hipFree(g->topo_dev);
-  if (g->decay_dev) (void)hipFree(g->decay_dev);
-  if (g->decay_idx_dev) (void)hipFree(g->decay_idx_dev);
-  if (g->decay_host) (void)hipHostFree(g->decay_host);
-  if (g->decay_idx_host) (void)hipHostFree(g->decay_idx_host);
+  for (auto& d : g->decay) {
+    if (d.dev) (void)hipFree(d.dev);
+    if (d.idx_dev) (void)hipFree(d.idx_dev);
+    if (d.host) (void)hipHostFree(d.host);
+    if (d.idx_host) (void)hipHostFree(d.idx_host);
+    if (d.done) (void)hipEventDestroy(d.done);
+    if (d.ready) (void)hipEventDestroy(d.ready);
+  }
+  if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
+  if (g->tm0) (void)hipEventDestroy(g->tm0);
+  if (g->tm1) (void)hipEventDestroy(g->tm1);
   if (g->ev0) (void)hipEventDestroy(g->ev0);
   if (g->ev1) (void)hipEventDestroy(g->ev1);
   if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -362,6 +378,28 @@ extern "C" int gmx_group_sync(gmx_group* g) {
   return GMX_OK;
 }
 
+// HIP events on the group's stream around any number of queued calls (bench.py brackets its
+// timed launches with them: GPU time without a host synchronisation per launch).
+extern "C" int gmx_group_timer_start(gmx_group* g) {
+  if (!g) return GMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(g->device));
+  if (!g->tm0) {
+    HIPCHK(hipEventCreate(&g->tm0));
+    HIPCHK(hipEventCreate(&g->tm1));
+  }
+  HIPCHK(hipEventRecord(g->tm0, g->stream));
+  return GMX_OK;
+}
+
+extern "C" int gmx_group_timer_stop(gmx_group* g, float* ms) {
+  if (!g || !ms || !g->tm0) return GMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(g->device));
+  HIPCHK(hipEventRecord(g->tm1, g->stream));
+  HIPCHK(hipEventSynchronize(g->tm1));
+  HIPCHK(hipEventElapsedTime(ms, g->tm0, g->tm1));
+  return GMX_OK;
+}
+
 // First factor of the learning-rate decay, float(0.9 / pow(1e-7 * steps_ + 0.8, 0.8))
 // (mixer.cpp:111).  It depends on the bit count only, so the host computes it once per bit
 // with the same libm pow the reference calls and ships it with the records; the per-row
@@ -371,7 +409,7 @@ static float decay_base(uint64_t steps) { return (float)(0.9 / pow(0.0000001 * s
 #include "gmx_session.inc"
 
 // Fill the group's decay tables for a run of T learning bits over streams [s0, s0+ns).
-static int prepare_decay(gmx_group* g, int s0, int ns, uint64_t T, int learn) {
+static int prepare_decay(gmx_group* g, int s0, int ns, uint64_t T, int learn, gmx_group::DecaySlot** out) {
   std::map<uint64_t, uint32_t> uniq;
   std::vector<uint32_t> idx(ns);
   for (int i = 0; i < ns; ++i) {
@@ -380,48 +418,56 @@ static int prepare_decay(gmx_group* g, int s0, int ns, uint64_t T, int learn) {
     if (it == uniq.end()) it = uniq.emplace(st, (uint32_t)uniq.size()).first;
     idx[i] = it->second;
   }
-  const size_t need = (size_t)uniq.size() * T + (size_t)ns;
-  if (need > g->decay_cap) {
-    // the previous run may still be reading the old tables
-    HIPCHK(hipStreamSynchronize(g->stream));
-    if (g->decay_dev) (void)hipFree(g->decay_dev);
-    if (g->decay_idx_dev) (void)hipFree(g->decay_idx_dev);
-    if (g->decay_host) (void)hipHostFree(g->decay_host);
-    if (g->decay_idx_host) (void)hipHostFree(g->decay_idx_host);
-    g->decay_dev = nullptr;
-    g->decay_idx_dev = nullptr;
-    g->decay_host = nullptr;
-    g->decay_idx_host = nullptr;
-    g->decay_cap = 0;
-    size_t cap = need + need / 2 + 1024;
-    HIPCHK(hipMalloc((void**)&g->decay_dev, cap * sizeof(float)));
-    HIPCHK(hipMalloc((void**)&g->decay_idx_dev, cap * sizeof(uint32_t)));
-    HIPCHK(hipHostMalloc((void**)&g->decay_host, cap * sizeof(float), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&g->decay_idx_host, cap * sizeof(uint32_t), hipHostMallocDefault));
-    g->decay_cap = cap;
-  } else {
-    // pinned staging is reused: make sure the previous upload has been consumed
-    HIPCHK(hipStreamSynchronize(g->stream));
+  gmx_group::DecaySlot& d = g->decay[g->run_seq++ & 1u];
+  *out = &d;
+  // the launch before last read this slot: it must be done before the staging is rewritten
+  if (d.busy) {
+    HIPCHK(hipEventSynchronize(d.done));
+    d.busy = false;
   }
+  const size_t need = (size_t)uniq.size() * T + (size_t)ns;
+  if (need > d.cap) {
+    if (d.dev) (void)hipFree(d.dev);
+    if (d.idx_dev) (void)hipFree(d.idx_dev);
+    if (d.host) (void)hipHostFree(d.host);
+    if (d.idx_host) (void)hipHostFree(d.idx_host);
+    d.dev = nullptr;
+    d.idx_dev = nullptr;
+    d.host = nullptr;
+    d.idx_host = nullptr;
+    d.cap = 0;
+    size_t cap = need + need / 2 + 1024;
+    HIPCHK(hipMalloc((void**)&d.dev, cap * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&d.idx_dev, cap * sizeof(uint32_t)));
+    HIPCHK(hipHostMalloc((void**)&d.host, cap * sizeof(float), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&d.idx_host, cap * sizeof(uint32_t), hipHostMallocDefault));
+    d.cap = cap;
+  }
+  if (!d.done) {
+    HIPCHK(hipEventCreateWithFlags(&d.done, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&d.ready, hipEventDisableTiming));
+  }
+  if (!g->copy_stream) HIPCHK(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
   for (auto& kv : uniq) {
-    float* tab = g->decay_host + (size_t)kv.second * T;
+    float* tab = d.host + (size_t)kv.second * T;
     if (learn)
       for (uint64_t t = 0; t < T; ++t) tab[t] = decay_base(kv.first + t);
     else
       for (uint64_t t = 0; t < T; ++t) tab[t] = 0.f;
   }
-  memcpy(g->decay_idx_host, idx.data(), ns * sizeof(uint32_t));
-  HIPCHK(hipMemcpyAsync(g->decay_dev, g->decay_host, uniq.size() * T * sizeof(float),
-                        hipMemcpyHostToDevice, g->stream));
-  HIPCHK(hipMemcpyAsync(g->decay_idx_dev, g->decay_idx_host, ns * sizeof(uint32_t),
-                        hipMemcpyHostToDevice, g->stream));
+  memcpy(d.idx_host, idx.data(), ns * sizeof(uint32_t));
+  HIPCHK(hipMemcpyAsync(d.dev, d.host, uniq.size() * T * sizeof(float), hipMemcpyHostToDevice, g->copy_stream));
+  HIPCHK(hipMemcpyAsync(d.idx_dev, d.idx_host, ns * sizeof(uint32_t), hipMemcpyHostToDevice, g->copy_stream));
+  HIPCHK(hipEventRecord(d.ready, g->copy_stream));
+  HIPCHK(hipStreamWaitEvent(g->stream, d.ready, 0));
   return GMX_OK;
 }
 
 static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint64_t T,
                       unsigned mode, float* kernel_ms) {
   if (T == 0) return GMX_OK;
-  int rc = prepare_decay(g, s0, ns, T, (mode & GMX_MODE_LEARN) ? 1 : 0);
+  gmx_group::DecaySlot* dec = nullptr;
+  int rc = prepare_decay(g, s0, ns, T, (mode & GMX_MODE_LEARN) ? 1 : 0, &dec);
   if (rc) return rc;
   GmxRunArgs a;
   memset(&a, 0, sizeof a);
@@ -430,8 +476,8 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
   a.mask = (b->flags & GMX_BATCH_MASK) ? b->d_mask : nullptr;
   a.ctx = b->d_ctx;
   a.bits = b->d_bits;
-  a.decay = g->decay_dev;
-  a.decay_idx = g->decay_idx_dev;
+  a.decay = dec->dev;
+  a.decay_idx = dec->idx_dev;
   a.p_out = b->d_p;
   a.out_all = (b->flags & GMX_BATCH_OUTPUTS) ? b->d_out : nullptr;
   a.latch_out = g->latch_out;
@@ -459,6 +505,8 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
     HIPCHK(gmx_launch_bank_kernel(g->topo_dev, &a, ns, g->lds_bytes, a.mask != nullptr, g->topo.l0,
                                   g->topo.l1, g->topo.n_skip, g->topo.has_final,
                                   g->topo.mx[g->topo.l0 - 1].stride, g->stream));
+  HIPCHK(hipEventRecord(dec->done, g->stream));
+  dec->busy = true;
   if (kernel_ms) {
     HIPCHK(hipEventRecord(g->ev1, g->stream));
     HIPCHK(hipEventSynchronize(g->ev1));

@@ -89,6 +89,10 @@ int gmx_group_n_inputs(const gmx_group* g);
 uint64_t gmx_group_bank_bytes(const gmx_group* g);   /* device bytes per stream */
 int gmx_group_reset(gmx_group* g);                   /* all banks back to the constructed state */
 int gmx_group_sync(gmx_group* g);                    /* wait for everything queued on its stream */
+/* HIP events on the group's stream: start is recorded behind what is queued so far, stop behind
+ * what was queued since; *ms = device time between the two (stop waits for it). */
+int gmx_group_timer_start(gmx_group* g);
+int gmx_group_timer_stop(gmx_group* g, float* ms);
 
 /* ---- per-bit surface: Predict / Perceive / Learn for one stream ------------------------ */
 /* 33 x Mixer::Predict + the final squash of Predictor::Predict (mixer.cpp:51-106,

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <stdint.h>
 
+typedef float vf4 __attribute__((ext_vector_type(4)));
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 __device__ __forceinline__ uint64_t mix(uint64_t x) {
@@ -16,7 +17,7 @@ __device__ __forceinline__ uint64_t mix(uint64_t x) {
   return x;
 }
 
-template <int MODE, int DEPTH>
+template <int MODE, int DEPTH, bool NT = false>
 __global__ void __launch_bounds__(256) rows_kernel(float4* buf, uint64_t n_rows, int iters, uint64_t seed) {
   const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) / 64;
   const int lane = threadIdx.x & 63;
@@ -28,12 +29,20 @@ __global__ void __launch_bounds__(256) rows_kernel(float4* buf, uint64_t n_rows,
     for (int d = 0; d < DEPTH; ++d) {
       r[d] = MODE == 2 ? ((wave + (uint64_t)(it + d) * n_waves) % n_rows)
                        : mix(seed + wave * 1000003ull + (uint64_t)(it + d)) % n_rows;
-      v[d] = buf[r[d] * 64 + lane];
+      if (NT) {
+        const vf4 q = __builtin_nontemporal_load((const vf4*)&buf[r[d] * 64 + lane]);
+        v[d] = make_float4(q.x, q.y, q.z, q.w);
+      } else {
+        v[d] = buf[r[d] * 64 + lane];
+      }
     }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       v[d].x += 1.0f;
-      if (MODE != 1) buf[r[d] * 64 + lane] = v[d];
+      if (MODE != 1) {
+        if (NT) __builtin_nontemporal_store((vf4){v[d].x, v[d].y, v[d].z, v[d].w}, (vf4*)&buf[r[d] * 64 + lane]);
+        else buf[r[d] * 64 + lane] = v[d];
+      }
       else if (v[d].x == 12345.678f) buf[lane] = v[d];
     }
   }
@@ -42,7 +51,7 @@ __global__ void __launch_bounds__(256) rows_kernel(float4* buf, uint64_t n_rows,
 int main(int argc, char** argv) {
   const double gib = argc > 1 ? atof(argv[1]) : 192.0;
   const int iters = argc > 2 ? atoi(argv[2]) : 2048;
-  const int mode = argc > 3 ? atoi(argv[3]) : 0;
+  const int mode = argc > 3 ? atoi(argv[3]) : 0;  // 3: random read+write with non-temporal hints
   const uint64_t bytes = (uint64_t)(gib * 1024.0 * 1024.0 * 1024.0) / 1024 * 1024;
   const uint64_t n_rows = bytes / 1024;
   float4* buf;
@@ -56,7 +65,8 @@ int main(int argc, char** argv) {
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
       CHECK(hipEventRecord(e0));
-      if (mode == 0) hipLaunchKernelGGL((rows_kernel<0, 8>), dim3(blocks), dim3(256), 0, 0, buf, n_rows, iters, 77ull + rep);
+      if (mode == 3) hipLaunchKernelGGL((rows_kernel<0, 8, true>), dim3(blocks), dim3(256), 0, 0, buf, n_rows, iters, 77ull + rep);
+      else if (mode == 0) hipLaunchKernelGGL((rows_kernel<0, 8>), dim3(blocks), dim3(256), 0, 0, buf, n_rows, iters, 77ull + rep);
       else if (mode == 1) hipLaunchKernelGGL((rows_kernel<1, 8>), dim3(blocks), dim3(256), 0, 0, buf, n_rows, iters, 77ull + rep);
       else hipLaunchKernelGGL((rows_kernel<2, 8>), dim3(blocks), dim3(256), 0, 0, buf, n_rows, iters, 77ull + rep);
       CHECK(hipEventRecord(e1));
@@ -67,7 +77,7 @@ int main(int argc, char** argv) {
     }
     const double moved = (double)blocks * 4 * iters * 1024.0 * (mode == 1 ? 1 : 2);
     printf("{\"pattern\": \"%s\", \"buffer_GiB\": %.0f, \"waves_per_simd\": %d, \"GB_per_s\": %.1f, \"ms\": %.3f}\n",
-           mode == 0 ? "random 1KiB row read+write" : mode == 1 ? "random 1KiB row read" : "sequential 1KiB rows read+write",
+           mode == 3 ? "random 1KiB row read+write, nontemporal" : mode == 0 ? "random 1KiB row read+write" : mode == 1 ? "random 1KiB row read" : "sequential 1KiB rows read+write",
            gib, waves_per_simd, moved / (best * 1e-3) / 1e9, best);
   }
   return 0;
