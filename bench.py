@@ -187,7 +187,7 @@ def main():
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
                 pm = json.load(open(f))
                 if (pm.get("streams"), pm.get("bits_per_stream")) == (S, T) and \
-                        pm.get("kernel", "").startswith(out["roofline"]["kernel"]):
+                        out["roofline"]["kernel"] in pm.get("kernel", ""):
                     out["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = os.path.relpath(f, ROOT)
                     break
