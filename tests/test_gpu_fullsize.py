@@ -1,0 +1,69 @@
+"""BASELINE.json configs[1] at the bench's full size (3072 streams x 512 bits, 194 GiB of gate
+tables) through properties that do not need the oracle to run 1.5 M bits: a launch split in two
+gives the same floats and the same banks; sampled streams equal the oracle run on the same seed;
+streams do not leak into each other."""
+import numpy as np
+import pytest
+
+from gmix_amd import topology
+
+pytestmark = pytest.mark.gpu
+
+S, T = 3072, 512
+GOLD = 0x9E3779B97F4A7C15
+SEED = 0x1234567
+
+
+def u32(x):
+    return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+def test_full_size_run_is_split_invariant_and_sampled_streams_match_the_oracle(gpu, oracle):
+    topo = topology.single(256, 1 << 16, 0.005)
+    try:
+        g = gpu.MixerGroup(topo, S)
+    except gpu.GmxError as e:  # a box with less free HBM than 194 GiB cannot host this case
+        pytest.skip(f"cannot allocate {S} banks: {e}")
+    b = gpu.Batch(g, T, outputs=False, mask=False)
+    samples = [0, 1, 777, 2048, S - 1]
+
+    def run(splits):
+        g.reset()
+        b.fill_synthetic(T, seed=SEED, restart=True)
+        # the device generator continues a stream across calls, so generate once, run in pieces
+        # by pointing successive launches at the same records: a split is two batches
+        if splits == 1:
+            g.run(b, T, learn=True)
+            b.download(T)
+            b.wait()
+            return b.p.copy()
+        half = gpu.Batch(g, T // 2, outputs=False, mask=False)
+        out = np.zeros((S, T), np.float32)
+        for k in range(2):
+            half.fill_synthetic(T // 2, seed=SEED, restart=(k == 0))
+            g.run(half, T // 2, learn=True)
+            half.download(T // 2)
+            half.wait()
+            out[:, k * (T // 2):(k + 1) * (T // 2)] = half.p
+        half.close()
+        return out
+
+    p1 = run(1)
+    banks1 = {s: g.export(s) for s in samples}
+    p2 = run(2)
+    assert np.array_equal(u32(p1), u32(p2))
+    for s in samples:
+        assert g.export(s) == banks1[s]
+    # every probability is a clamped logistic
+    assert np.isfinite(p1).all() and p1.min() >= np.float32(1e-4) and p1.max() <= np.float32(1) - np.float32(1e-4)
+    # sampled streams against the oracle, from the seed alone
+    for s in samples:
+        pred, act, ctx, bits = oracle.synth(256, 1, T, seed=(SEED + s * GOLD) % (1 << 64))
+        ob = oracle.Bank(256, topo.skip, topo.mixers)
+        p_ref, _ = ob.run(pred, act, ctx, bits)
+        assert np.array_equal(u32(p1[s]), u32(p_ref)), s
+        assert banks1[s] == (ob.export_long(), ob.export_short()), s
+    # distinct seeds give distinct streams (no stream reads another's rows or records)
+    assert len({p1[s].tobytes() for s in samples}) == len(samples)
+    b.close()
+    g.close()
