@@ -118,3 +118,28 @@ def test_stock_kernels_leave_the_reserved_registers_alone():
     subprocess.check_call([sys.executable, os.path.join(ROOT, "gmix_amd", "csrc", "gen_stock_asm.py")],
                           stdout=subprocess.DEVNULL)
     assert open(inc).read() == before
+
+
+def test_indirect_descriptions_are_validated_before_any_device_is_touched():
+    """gmx_indirect_create checks its arguments on the host first: bad tables, clashing slots and
+    missing next-state tables are GMX_ERR_INVALID with or without a GPU."""
+    from gmix_amd._lib import IndirectDesc
+    L = _lib.lib()
+    tabs = (C.c_uint8 * 512)()
+    h = C.c_void_p()
+
+    def create(descs, ns=tabs, rm=tabs, streams=1):
+        arr = (IndirectDesc * max(1, len(descs)))(*[IndirectDesc(*d) for d in descs])
+        return L.gmx_indirect_create(C.byref(h), arr, len(descs), ns, rm, streams, 0)
+
+    assert create([]) == -1                                   # no models
+    assert create([(0, 0.02, 0, 1)]) == -1                    # empty table
+    assert create([(1 << 24, 0.02, 0, 1)]) == -1              # 256*table_size+1 must fit 32 bits
+    assert create([(256, 0.02, 3, 3)]) == -1                  # one slot for both predictions
+    assert create([(256, 0.02, 0, 1), (256, 0.02, 1, 2)]) == -1  # two models on one slot
+    assert create([(256, 0.02, -1, 1)]) == -1
+    assert create([(256, 0.02, 0, 1)], ns=None) == -1
+    assert create([(256, 0.02, 0, 1)], streams=0) == -1
+    assert create([(256, 0.02, 2 * i, 2 * i + 1) for i in range(65)]) == -1   # more than 64 models
+    if gmix_amd.device_count() == 0:
+        assert create([(256, 0.02, 0, 1)]) == -4              # valid, but nothing to run it on
