@@ -322,3 +322,80 @@ def read_ind_dump(path):
     assert o + ll == len(raw)
     return dict(K=K, T=T, D=D, ns_next=ns_next, rm_next=rm_next, pred=pred, active=act, h64=h64,
                 usage=usage, long=long_b)
+
+
+# ---- LSTM byte model (oracle/gmx_oracle_lstm.c) -------------------
+def _lstm_lib():
+    L = lib()
+    if not getattr(L, "_lstm_ready", False):
+        L.gmxo_lstm_create.restype = C.c_void_p
+        L.gmxo_lstm_destroy.argtypes = [C.c_void_p]
+        L.gmxo_lstm_get_weights.argtypes = [C.c_void_p, C.c_void_p]
+        L.gmxo_lstm_set_weights.argtypes = [C.c_void_p, C.c_void_p]
+        L.gmxo_lstm_model_predict.restype = C.c_int
+        L.gmxo_lstm_model_predict.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p,
+                                              C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p]
+        L.gmxo_lstm_model_learn.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.gmxo_lstm_state_hash.restype = C.c_uint64
+        L.gmxo_lstm_state_hash.argtypes = [C.c_void_p]
+        L.gmxo_lstm_weights_hash.restype = C.c_uint64
+        L.gmxo_lstm_weights_hash.argtypes = [C.c_void_p, C.c_int]
+        L.gmxo_lstm_run_synth.restype = C.c_uint64
+        L.gmxo_lstm_run_synth.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
+        L.gmxo_srand.argtypes = [C.c_uint]
+        L._lstm_ready = True
+    return L
+
+
+class LstmModel:
+    """The reference's LstmModel (Lstm(256, 256, 50, 1, 100, 0.03, 10)), weights initialised from
+    rand() after srand(seed) exactly like the reference's constructor chain."""
+
+    def __init__(self, srand_seed=0xDEADBEEF):
+        self.L = _lstm_lib()
+        self.L.gmxo_srand(srand_seed)
+        self.h = self.L.gmxo_lstm_create()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.gmxo_lstm_destroy(self.h)
+            self.h = None
+
+    def weights_hash(self, with_output_layer=False):
+        return int(self.L.gmxo_lstm_weights_hash(self.h, 1 if with_output_layer else 0))
+
+    def run_synth(self, n_bytes, seed=0, mask=255, dump=0):
+        """Drive the model with oracle/gmx_lstm_synth.h like the reference harness does; returns
+        (fnv over all bits, predictions[dump,8], active[dump,8], context[dump])."""
+        pred = np.zeros((dump, 8), np.float32)
+        act = np.zeros((dump, 8), np.uint8)
+        ctx = np.zeros(dump, np.uint32)
+        h = self.L.gmxo_lstm_run_synth(self.h, n_bytes, seed, mask, dump, _p(pred), _p(act), _p(ctx))
+        return int(h), pred, act, ctx
+
+
+def read_lstm_dump(path):
+    """GMXL file of oracle/ref_build/ref_lstm_harness."""
+    raw = open(path, "rb").read()
+    magic, N, D = struct.unpack_from("<3I", raw, 0)
+    assert magic == 0x4C584D47
+    (hw,) = struct.unpack_from("<Q", raw, 12)
+    o = 20
+    pred = np.zeros((D, 8), np.float32)
+    act = np.zeros((D, 8), np.uint8)
+    ctx = np.zeros(D, np.uint32)
+    for n in range(D):
+        for k in range(8):
+            pred[n, k], act[n, k] = struct.unpack_from("<fB", raw, o)
+            o += 5
+            if k == 0:
+                (ctx[n],) = struct.unpack_from("<I", raw, o)
+                o += 4
+    h, hl, usage, short_size, hs = struct.unpack_from("<5Q", raw, o)
+    o += 40
+    top, mid, bot = struct.unpack_from("<3i", raw, o)
+    probs = np.frombuffer(raw, np.float32, 256, o + 12).copy()
+    assert o + 12 + 1024 == len(raw)
+    return dict(N=N, D=D, init_weights_hash=hw, pred=pred, active=act, ctx=ctx, h64=h, long_hash=hl, usage=usage,
+                short_size=short_size, short_hash=hs, top=top, mid=mid, bot=bot, probs=probs)

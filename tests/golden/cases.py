@@ -50,3 +50,13 @@ IND_CASES = {
     "ind_long": (lambda: [(256, 0.02), (65536, 0.02), (32768, 0.005), (256, 0.005), (65536, 0.02), (1, 0.02)],
                  1_000_000, 0, dict(ctx_mod=(50, 0, 3000, 7), seed=99)),
 }
+
+
+# LSTM byte model, through oracle/_ref/ref_lstm_harness:
+# name -> (bytes, bytes fully dumped, kwargs of gmx_lstm_synth.h)
+LSTM_CASES = {
+    "lstm_short": (300, 300, dict()),                       # three backward passes, every bit dumped
+    "lstm_alphabet16": (5000, 100, dict(seed=7, mask=15)),  # a learnable 16-symbol stream
+    "lstm_long": (20000, 0, dict(seed=99)),                 # 200 backward passes, checksums only
+    "lstm_update_limit": (305000, 0, dict(seed=3, mask=63)),  # Adam's step count reaches update_limit_ = 3000
+}

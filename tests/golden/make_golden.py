@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(HERE))
 
-from golden.cases import CASES, IND_CASES  # noqa: E402
+from golden.cases import CASES, IND_CASES, LSTM_CASES  # noqa: E402
 from oracle import gmxo  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref")
@@ -93,6 +93,24 @@ def run_ind_case(name):
     print(f"{name}: K={len(models)} T={T} dump={dump} h64={d['h64']:016x} long={len(ind_b)}B")
 
 
+def run_lstm_case(name):
+    n_bytes, dump, kw = LSTM_CASES[name]
+    args = [os.path.join(REF, "ref_lstm_harness"), "--bytes", str(n_bytes), "--dump", str(dump),
+            "--seed", str(kw.get("seed", 0)), "--mask", str(kw.get("mask", 255))]
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "d.bin")
+        subprocess.run(args + ["--out", out], check=True, stdout=subprocess.DEVNULL)
+        d = gmxo.read_lstm_dump(out)
+    meta = dict(name=name, bytes=n_bytes, dump=dump, synth=kw, h64=int(d["h64"]),
+                init_weights_hash=int(d["init_weights_hash"]), long_hash=int(d["long_hash"]),
+                usage=int(d["usage"]), short_size=int(d["short_size"]), short_hash=int(d["short_hash"]),
+                top=int(d["top"]), mid=int(d["mid"]), bot=int(d["bot"]),
+                source="oracle/_ref/ref_lstm_harness (reference LstmModel after srand(0xDEADBEEF), g++ -O2 strict)")
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), meta=json.dumps(meta), pred=d["pred"].view(np.uint32),
+                        active=d["active"], ctx=d["ctx"], probs=d["probs"].view(np.uint32))
+    print(f"{name}: bytes={n_bytes} dump={dump} h64={d['h64']:016x} long={d['long_hash']:016x}")
+
+
 def run_trace(n_bytes=300):
     """Whole reference Predictor over the first bytes of dictionary/english.dic."""
     src = "/root/reference/dictionary/english.dic"
@@ -146,11 +164,13 @@ def run_trace(n_bytes=300):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + list(IND_CASES) + ["trace"])
+    names = sys.argv[1:] or (list(CASES) + list(IND_CASES) + list(LSTM_CASES) + ["trace"])
     for nm in names:
         if nm == "trace":
             run_trace()
         elif nm in IND_CASES:
             run_ind_case(nm)
+        elif nm in LSTM_CASES:
+            run_lstm_case(nm)
         else:
             run_case(nm)
