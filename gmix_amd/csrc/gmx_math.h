@@ -127,4 +127,162 @@ GMX_HD float gmx_clamp_prob(float prob) {
 }
 GMX_HD float gmx_squash_clamp(float out) { return gmx_clamp_prob(gmx_logistic(out)); }
 
+// ---- logf, expm1f, tanhf: what the LSTM byte model needs (models/lstm-layer.cpp:208, :215;
+// Sigmoid::Logit, mixer/sigmoid.cpp:7-13) ------------------------------------------------------
+//
+// logf: glibc >= 2.28 (sysdeps/ieee754/flt-32/e_logf.c, Arm Optimized Routines): x = 2^k z with
+// z in [0x1.66p-1, 0x1.66p0) split in 16 intervals; r = z*invc - 1 from a table of (1/c, log c),
+// cubic in r, all in double, one final rounding.  As with expf the FMA-contracted build
+// (__logf_fma) is what an FMA-capable x86-64 runs; the contractions are spelled out.  The table
+// is the published one (logf_data.c); tests/test_math.py compares gmx_logf with the machine's
+// libm over all 2^32 inputs.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__
+#endif
+static const uint64_t gmx_logf_tab[16][2] = {  // {invc, logc} as raw doubles
+    {0x3ff661ec79f8f3beull, 0xbfd57bf7808caadeull}, {0x3ff571ed4aaf883dull, 0xbfd2bef0a7c06ddbull},
+    {0x3ff49539f0f010b0ull, 0xbfd01eae7f513a67ull}, {0x3ff3c995b0b80385ull, 0xbfcb31d8a68224e9ull},
+    {0x3ff30d190c8864a5ull, 0xbfc6574f0ac07758ull}, {0x3ff25e227b0b8ea0ull, 0xbfc1aa2bc79c8100ull},
+    {0x3ff1bb4a4a1a343full, 0xbfba4e76ce8c0e5eull}, {0x3ff12358f08ae5baull, 0xbfb1973c5a611cccull},
+    {0x3ff0953f419900a7ull, 0xbfa252f438e10c1eull}, {0x3ff0000000000000ull, 0x0000000000000000ull},
+    {0x3fee608cfd9a47acull, 0x3faaa5aa5df25984ull}, {0x3feca4b31f026aa0ull, 0x3fbc5e53aa362eb4ull},
+    {0x3feb2036576afce6ull, 0x3fc526e57720db08ull}, {0x3fe9c2d163a1aa2dull, 0x3fcbc2860d224770ull},
+    {0x3fe886e6037841edull, 0x3fd1058bc8a07ee1ull}, {0x3fe767dcf5534862ull, 0x3fd4043057b6ee09ull}};
+
+GMX_HD float gmx_logf(float x) {
+  const double kLn2 = 0x1.62e42fefa39efp-1;
+  const double kA0 = -0x1.00ea348b88334p-2, kA1 = 0x1.5575b0be00b6ap-2, kA2 = -0x1.ffffef20a4123p-2;
+  uint32_t ix = gmx_f2u(x);
+  if (ix == 0x3f800000u) return 0.0f;
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+    if (ix * 2u == 0) return gmx_u2f(0xff800000u);                                  // log(+-0) = -inf
+    if (ix == 0x7f800000u) return x;                                                // log(inf) = inf
+    if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return gmx_u2f(0x7fc00000u) + (x != x ? x : 0.0f);  // NaN
+    ix = gmx_f2u(x * 0x1p23f);                                                      // subnormal: normalise
+    ix -= 23u << 23;
+  }
+  const uint32_t tmp = ix - 0x3f330000u;
+  const uint32_t i = (tmp >> 19) & 15u;
+  const int32_t k = (int32_t)tmp >> 23;
+  const uint32_t iz = ix - (tmp & 0xff800000u);
+  const double invc = gmx_u2d(gmx_logf_tab[i][0]), logc = gmx_u2d(gmx_logf_tab[i][1]);
+  const double z = (double)gmx_u2f(iz);
+  const double r = gmx_fma(z, invc, -1.0);
+  const double y0 = gmx_fma((double)k, kLn2, logc);
+  const double r2 = r * r;
+  double y = gmx_fma(kA1, r, kA2);
+  y = gmx_fma(kA0, r2, y);
+  y = gmx_fma(y, r2, y0 + r);
+  return (float)y;
+}
+
+// Sigmoid::Logit (mixer/sigmoid.cpp:7-13): the comparisons and the clamp constants are double
+// literals; the division and 1 - p are float.
+GMX_HD float gmx_logit(float p) {
+  if ((double)p < 0.0001) p = (float)0.0001;
+  else if ((double)p > 0.9999) p = (float)0.9999;
+  return gmx_logf(p / (1 - p));
+}
+
+// expm1f: glibc's fdlibm port (sysdeps/ieee754/flt-32/s_expm1f.c), plain float arithmetic,
+// no fused operations (there is no FMA build of it).
+GMX_HD float gmx_expm1f(float x) {
+  const float one = 1.0f, huge = 1.0e+30f, tiny = 1.0e-30f;
+  const float o_threshold = 8.8721679688e+01f, ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f,
+              invln2 = 1.4426950216e+00f;
+  const float Q1 = -3.3333335072e-02f, Q2 = 1.5873016091e-03f, Q3 = -7.9365076090e-05f,
+              Q4 = 4.0082177293e-06f, Q5 = -2.0109921195e-07f;
+  float y, hi, lo, c = 0.0f, t, e, hxs, hfx, r1;
+  int32_t k;
+  uint32_t hx = gmx_f2u(x);
+  const uint32_t xsb = hx & 0x80000000u;
+  hx &= 0x7fffffffu;
+  if (hx >= 0x4195b844u) {        // |x| >= 27 ln2
+    if (hx >= 0x42b17218u) {      // |x| >= 88.72
+      if (hx > 0x7f800000u) return x + x;
+      if (hx == 0x7f800000u) return xsb == 0 ? x : -1.0f;
+      if (x > o_threshold) return huge * huge;
+    }
+    if (xsb != 0) return tiny - one;
+  }
+  if (hx > 0x3eb17218u) {         // |x| > 0.5 ln2
+    if (hx < 0x3F851592u) {       // |x| < 1.5 ln2
+      if (xsb == 0) {
+        hi = x - ln2_hi;
+        lo = ln2_lo;
+        k = 1;
+      } else {
+        hi = x + ln2_hi;
+        lo = -ln2_lo;
+        k = -1;
+      }
+    } else {
+      k = (int32_t)(invln2 * x + (xsb == 0 ? 0.5f : -0.5f));
+      t = (float)k;
+      hi = x - t * ln2_hi;
+      lo = t * ln2_lo;
+    }
+    x = hi - lo;
+    c = (hi - x) - lo;
+  } else if (hx < 0x33000000u) {  // |x| < 2^-25
+    t = huge + x;
+    return x - (t - (huge + x));
+  } else {
+    k = 0;
+  }
+  hfx = 0.5f * x;
+  hxs = x * hfx;
+  r1 = one + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+  t = 3.0f - r1 * hfx;
+  e = hxs * ((r1 - t) / (6.0f - x * t));
+  if (k == 0) return x - (x * e - hxs);
+  e = (x * (e - c) - c);
+  e -= hxs;
+  if (k == -1) return 0.5f * (x - e) - 0.5f;
+  if (k == 1) {
+    if (x < -0.25f) return -2.0f * (e - (x + 0.5f));
+    return one + 2.0f * (x - e);
+  }
+  if (k <= -2 || k > 56) {
+    y = one - (e - x);
+    y = gmx_u2f(gmx_f2u(y) + ((uint32_t)k << 23));
+    return y - one;
+  }
+  if (k < 23) {
+    t = gmx_u2f(0x3f800000u - (0x1000000u >> k));  // 1 - 2^-k
+    y = t - (e - x);
+    y = gmx_u2f(gmx_f2u(y) + ((uint32_t)k << 23));
+  } else {
+    t = gmx_u2f((uint32_t)(0x7f - k) << 23);       // 2^-k
+    y = x - (e + t);
+    y += one;
+    y = gmx_u2f(gmx_f2u(y) + ((uint32_t)k << 23));
+  }
+  return y;
+}
+
+// tanhf: glibc's fdlibm port (sysdeps/ieee754/flt-32/s_tanhf.c) on top of expm1f.
+GMX_HD float gmx_tanhf(float x) {
+  const float one = 1.0f, two = 2.0f, tiny = 1.0e-30f;
+  float t, z;
+  const uint32_t jx = gmx_f2u(x);
+  const uint32_t ix = jx & 0x7fffffffu;
+  if (ix >= 0x7f800000u) return (jx >> 31) == 0 ? one / x + one : one / x - one;
+  if (ix < 0x41b00000u) {  // |x| < 22
+    if (ix == 0) return x;
+    if (ix < 0x24000000u) return x * (one + x);  // |x| < 2^-55
+    const float ax = gmx_u2f(ix);
+    if (ix >= 0x3f800000u) {
+      t = gmx_expm1f(two * ax);
+      z = one - two / (t + two);
+    } else {
+      t = gmx_expm1f(-two * ax);
+      z = -t / (t + two);
+    }
+  } else {
+    z = one - tiny;
+  }
+  return (jx >> 31) == 0 ? z : -z;
+}
+
 #endif  // GMX_MATH_H_

@@ -19,7 +19,8 @@ def mc():
         subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", src,
                                "-o", so, "-lm"])
     L = C.CDLL(so)
-    for f in (L.gmx_check_expf_range, L.gmx_check_logistic_range):
+    for f in (L.gmx_check_expf_range, L.gmx_check_logistic_range, L.gmx_check_logf_range,
+              L.gmx_check_expm1f_range, L.gmx_check_tanhf_range):
         f.restype = C.c_uint64
         f.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
     L.gmx_host_logistic_array.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
@@ -48,3 +49,13 @@ def test_squash_clamp_matches_oracle(mc, oracle):
     ref = np.array([oracle.lib().gmxo_squash_clamp(float(v)) for v in x], np.float32)
     assert np.array_equal(y.view(np.uint32), ref.view(np.uint32))
     assert y.min() == np.float32(0.0001) and y.max() == np.float32(1) - np.float32(0.0001)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("fn", ["logf", "expm1f", "tanhf"])
+def test_lstm_math_equals_libm_everywhere(mc, fn):
+    """gmx_logf / gmx_expm1f / gmx_tanhf (what the LSTM byte model calls through Sigmoid::Logit,
+    tanh(float) and tanh(valarray)) against the machine's libm for every float."""
+    bad = np.zeros(16, np.uint32)
+    n = getattr(mc, f"gmx_check_{fn}_range")(0, 0xFFFFFFFF, bad.ctypes.data, 16)
+    assert n == 0, (n, [hex(b) for b in bad[:min(n, 16)]])
