@@ -5,6 +5,7 @@ from . import topology
 from ._lib import ABI_SYMBOLS, LIB_PATH, GmxError, build
 from .bank import Batch, MixerGroup, Topology, device_count
 from .indirect import IndirectBatch, IndirectGroup
+from .lstm import LstmBatch, LstmGroup
 
 __all__ = ["topology", "ABI_SYMBOLS", "LIB_PATH", "GmxError", "build", "Batch", "MixerGroup",
-           "Topology", "device_count", "IndirectGroup", "IndirectBatch"]
+           "Topology", "device_count", "IndirectGroup", "IndirectBatch", "LstmGroup", "LstmBatch"]

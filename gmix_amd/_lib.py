@@ -117,6 +117,27 @@ def lib():
     L.gmx_indirect_import.argtypes = [vp, i32, vp, C.c_size_t]
     L.gmx_indirect_copy.argtypes = [vp, i32, vp, i32]
     L.gmx_indirect_memory_usage.argtypes = [vp, i32, C.POINTER(u64)]
+    L.gmx_lstm_create.argtypes = [C.POINTER(vp), i32, i32]
+    L.gmx_lstm_destroy.argtypes = [vp]
+    L.gmx_lstm_destroy.restype = None
+    for f in (L.gmx_lstm_n_streams, L.gmx_lstm_reset, L.gmx_lstm_sync):
+        f.argtypes = [vp]
+    L.gmx_lstm_bank_bytes.argtypes = [vp]
+    L.gmx_lstm_bank_bytes.restype = u64
+    L.gmx_lstm_set_weights.argtypes = [vp, i32, vp]
+    L.gmx_lstm_get_weights.argtypes = [vp, i32, vp, vp]
+    L.gmx_lstm_batch_create.argtypes = [C.POINTER(vp), vp, u64]
+    L.gmx_lstm_batch_destroy.argtypes = [vp]
+    L.gmx_lstm_batch_destroy.restype = None
+    for name in ("gmx_lstm_batch_ppm", "gmx_lstm_batch_bytes", "gmx_lstm_batch_predictions",
+                 "gmx_lstm_batch_active", "gmx_lstm_batch_contexts"):
+        f = getattr(L, name)
+        f.argtypes = [vp]
+        f.restype = vp
+    L.gmx_lstm_batch_upload.argtypes = [vp, u64]
+    L.gmx_lstm_batch_download.argtypes = [vp, u64]
+    L.gmx_lstm_batch_wait.argtypes = [vp]
+    L.gmx_lstm_run.argtypes = [vp, vp, u64, i32, C.POINTER(C.c_float)]
     L.gmx_debug_math_probe.argtypes = [i32, vp, vp, u64, i32]
     L.gmx_debug_math_range.argtypes = [i32, u64, u64, i32, C.POINTER(C.c_ulonglong)]
     _LIB = L
@@ -145,4 +166,9 @@ ABI_SYMBOLS = [
     "gmx_ind_batch_predictions", "gmx_ind_batch_active", "gmx_ind_batch_upload", "gmx_ind_batch_download",
     "gmx_ind_batch_wait", "gmx_ind_batch_fill_synthetic", "gmx_indirect_run", "gmx_indirect_export",
     "gmx_indirect_import", "gmx_indirect_copy", "gmx_indirect_memory_usage",
+    "gmx_lstm_create", "gmx_lstm_destroy", "gmx_lstm_n_streams", "gmx_lstm_bank_bytes", "gmx_lstm_reset",
+    "gmx_lstm_sync", "gmx_lstm_set_weights", "gmx_lstm_get_weights", "gmx_lstm_batch_create",
+    "gmx_lstm_batch_destroy", "gmx_lstm_batch_ppm", "gmx_lstm_batch_bytes", "gmx_lstm_batch_predictions",
+    "gmx_lstm_batch_active", "gmx_lstm_batch_contexts", "gmx_lstm_batch_upload", "gmx_lstm_batch_download",
+    "gmx_lstm_batch_wait", "gmx_lstm_run",
 ]

@@ -131,4 +131,50 @@ struct GmxIndRunArgs {
   int32_t mx_n_pad, mx_mask_words;
 };
 
+// ---- LSTM byte model (models/lstm*.cpp) -----------------------
+// The reference builds Lstm(256, 256, 50, 1, 100, 0.03, 10) (lstm-model.cpp:7).  One stream's
+// state, in floats (u32 where noted), every [cell] vector padded to 64:
+#define GMX_L_NI 256
+#define GMX_L_NO 256
+#define GMX_L_NC 50
+#define GMX_L_H 100
+#define GMX_L_LIN 307     // input (256) + hidden (50) + bias
+#define GMX_L_LINP 320
+#define GMX_L_W 563       // one-hot symbol column (256) + layer input (307)
+#define GMX_L_HID 51
+#define GMX_L_CP 64
+
+struct GmxLstmGateOff {   // float offsets inside a bank
+  uint64_t weights, update, m, v;                 // [W][CP]   (row = input index, column = cell)
+  uint64_t gamma, gamma_u, gamma_m, gamma_v, beta, beta_u, beta_m, beta_v, error;  // [CP]
+  uint64_t state, norm;                           // [H][CP]
+  uint64_t ivar;                                  // [H]
+};
+
+struct GmxLstmDev {
+  uint64_t out_layer;                             // [H][HID][NO]  (LongTermMemory::lstm_output_layer, transposed)
+  GmxLstmGateOff gate[3];                         // forget gate, input node, output gate
+  uint64_t state, state_error, stored_error;      // [CP]
+  uint64_t tanh_state, input_gate_state, last_state;  // [H][CP]
+  uint64_t hidden, hidden_error;                  // [CP]
+  uint64_t layer_input;                           // [H][LINP]
+  uint64_t output;                                // [H][NO]
+  uint64_t input_history;                         // u32 [H]
+  uint64_t probs;                                 // [NO]  LstmModel::probs_
+  uint64_t scal;                                  // u32 [16]: epoch, layer epoch, update_steps, last_byte, context, prediction bits
+  uint64_t bank_floats;
+};
+
+struct GmxLstmRunArgs {
+  float* banks;
+  const float* ppm;        // [S][*][256]
+  const uint8_t* bytes;    // [S][*]
+  const float* adam;       // [S][max_bptt][4]: alpha, 1 - beta1^t, 1 - beta2^t for the stream's next backward passes
+  float* pred_out;         // [S][*][8]
+  uint8_t* act_out;        // [S][*][8]
+  uint32_t* ctx_out;       // [S][*]
+  uint64_t rec_stride, n_bytes;
+  uint32_t learn, max_bptt;
+};
+
 #endif  // GMX_INTERNAL_H_

@@ -1,0 +1,390 @@
+// gmx_lstm.hip -- the reference's LSTM byte model (models/lstm-model.cpp, lstm.cpp,
+// lstm-layer.cpp) for many streams: one 256-thread workgroup per stream, bytes in sequence.
+//
+// Every float operation of the reference is performed once, in the reference's order: the dot
+// products are serial chains (mul, then add), expression sums run from the last element down
+// and plain valarray sums from the first up (libstdc++), layer norm / activations / Adam are the
+// same elementwise formulas; tanhf, expf, logf are gmx_math.h's restatements of the glibc
+// routines the reference calls.  Parallelism comes from what the reference leaves independent:
+//   * the 3 gates x 50 cells of a forward pass: one wave per gate, one lane per cell, the gate
+//     weights stored input-major ([input][cell]) so that the 307-step chains of a wave read
+//     coalesced rows;
+//   * the 256 outputs of the output layer (51-step chains, one thread each) and of its SGD step;
+//   * in the backward pass the 50 hidden-error chains (256 steps each), the three gates, and the
+//     563 x 50 independent accumulators / Adam updates of each gate;
+//   * the 8 bit predictions of a byte (their ranges follow from the byte), one lane each.
+// This is the first, correctness-first version of this path: no LDS weight staging, barriers
+// between phases, scalar loads.  oracle/gmx_oracle_lstm.c is the line-by-line specification.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gmx_internal.h"
+#include "gmx_math.h"
+
+namespace {
+
+constexpr int NI = GMX_L_NI, NO = GMX_L_NO, NC = GMX_L_NC, H = GMX_L_H, LIN = GMX_L_LIN, LINP = GMX_L_LINP,
+              W = GMX_L_W, HID = GMX_L_HID, CP = GMX_L_CP;
+constexpr float kLearningRate = 0.03f, kClip = 10.0f;
+constexpr uint32_t kUpdateLimit = 3000;
+
+struct Lds {
+  float xin[LINP];        // layer input of the epoch at hand
+  float hid[CP];          // Lstm::hidden_ (hid[50] = 1)
+  float herr[CP];         // Lstm::hidden_error_
+  float probs[NO];        // LstmModel::probs_ / softmax scratch
+  float err[NO];          // output-layer error of an epoch
+  float nrm[3][CP];       // per gate: pre-norm sums / products for the ordered reductions
+  float act[3][CP];       // per gate: activated state of the forward pass / final errors backward
+  float fsum[3][CP];
+  float red[8];
+  uint32_t ired[4];
+  uint64_t exptab[32];
+};
+
+__device__ __forceinline__ float clipf(float a) { return a < -kClip ? -kClip : (a > kClip ? kClip : a); }
+
+}  // namespace
+
+__global__ void __launch_bounds__(256)
+gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
+  __shared__ Lds L;
+  const GmxLstmDev& dv = *dvp;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int s = blockIdx.x;
+  float* const B = a.banks + (uint64_t)s * dv.bank_floats;
+  uint32_t* const scal = (uint32_t*)(B + dv.scal);
+  uint32_t* const hist = (uint32_t*)(B + dv.input_history);
+  float* const out_layer = B + dv.out_layer;
+  const float* const ppm_s = a.ppm + (uint64_t)s * a.rec_stride * NI;
+  const uint8_t* const bytes_s = a.bytes + (uint64_t)s * a.rec_stride;
+  const float* const adam_s = a.adam + (uint64_t)s * a.max_bptt * 4;
+  float* const pred_s = a.pred_out + (uint64_t)s * a.rec_stride * 8;
+  uint8_t* const act_s = a.act_out + (uint64_t)s * a.rec_stride * 8;
+  uint32_t* const ctx_s = a.ctx_out + (uint64_t)s * a.rec_stride;
+
+  if (tid < 32) L.exptab[tid] = gmx_exp2f_tab[tid];
+  if (tid < CP) {
+    L.hid[tid] = (B + dv.hidden)[tid];
+    L.herr[tid] = (B + dv.hidden_error)[tid];
+  }
+  L.probs[tid] = (B + dv.probs)[tid];
+  uint32_t epoch = scal[0], l_epoch = scal[1], update_steps = scal[2], last_byte = scal[3], context = scal[4];
+  float prediction = __uint_as_float(scal[5]);
+  uint32_t bptt_done = 0;
+  __syncthreads();
+
+  for (uint64_t n = 0; n < a.n_bytes; ++n) {
+    const uint32_t byte = bytes_s[n];
+    // ======================= Lstm::Predict (lstm.cpp:95-123) ================================
+    {
+      const uint32_t e = epoch, le = l_epoch;
+      float* const lin = B + dv.layer_input + (uint64_t)e * LINP;
+      // SetInput + the recurrent part of the layer input (lstm.cpp:45-50, :98-100)
+      L.xin[tid] = ppm_s[n * NI + tid];
+      if (tid < NC) L.xin[NI + tid] = L.hid[tid];
+      if (tid == 0) L.xin[LIN - 1] = 1.0f;
+      if (tid < NC) (B + dv.last_state + (uint64_t)le * CP)[tid] = (B + dv.state)[tid];  // lstm-layer.cpp:200
+      __syncthreads();
+      for (int j = tid; j < LIN; j += 256) lin[j] = L.xin[j];
+      // LstmLayer::ForwardPass(NeuronLayer&) (lstm-layer.cpp:221-241): wave = gate, lane = cell
+      if (wave < 3 && lane < NC) {
+        const GmxLstmGateOff& g = dv.gate[wave];
+        const float* w = B + g.weights;
+        float f = w[(uint64_t)last_byte * CP + lane];
+        for (int j = 0; j < LIN; ++j) f += L.xin[j] * w[(uint64_t)(NO + j) * CP + lane];
+        L.nrm[wave][lane] = f;
+      }
+      __syncthreads();
+      if (wave < 3 && lane == 0) {
+        float sq = L.nrm[wave][NC - 1] * L.nrm[wave][NC - 1];  // expression .sum(): last element first
+        for (int i = NC - 2; i >= 0; --i) sq += L.nrm[wave][i] * L.nrm[wave][i];
+        const float iv = 1.0f / sqrtf((sq / (float)NC) + 1e-5f);
+        L.red[wave] = iv;
+        (B + dv.gate[wave].ivar)[le] = iv;
+      }
+      __syncthreads();
+      if (wave < 3 && lane < NC) {
+        const GmxLstmGateOff& g = dv.gate[wave];
+        const float nv = L.nrm[wave][lane] * L.red[wave];
+        (B + g.norm + (uint64_t)le * CP)[lane] = nv;
+        float st = nv * (B + g.gamma)[lane] + (B + g.beta)[lane];
+        st = wave == 1 ? gmx_tanhf(st) : gmx_logistic_tab(st, L.exptab);  // lstm-layer.cpp:205-211
+        (B + g.state + (uint64_t)le * CP)[lane] = st;
+        L.act[wave][lane] = st;
+      }
+      __syncthreads();
+      if (tid < NC) {  // lstm-layer.cpp:212-217
+        const float f = L.act[0][tid];
+        const float igs = 1.0f - f;
+        float st = (B + dv.state)[tid] * f;
+        st = st + L.act[1][tid] * igs;
+        const float ts = gmx_tanhf(st);
+        (B + dv.input_gate_state + (uint64_t)le * CP)[tid] = igs;
+        (B + dv.state)[tid] = st;
+        (B + dv.tanh_state + (uint64_t)le * CP)[tid] = ts;
+        L.hid[tid] = L.act[2][tid] * ts;
+      }
+      __syncthreads();
+      // output layer + softmax (lstm.cpp:106-118): thread = output symbol
+      const float* ol = out_layer + (uint64_t)e * HID * NO;
+      float sum = 0.0f;
+      for (int j = 0; j < HID; ++j) sum += L.hid[j] * ol[(uint64_t)j * NO + tid];
+      // max_out = max(0, every sum): order does not matter for a maximum
+      float mx = sum > 0.0f ? sum : 0.0f;
+      for (int o = 32; o > 0; o >>= 1) {
+        const float other = __shfl_xor(mx, o);
+        mx = other > mx ? other : mx;
+      }
+      if (lane == 0) L.red[4 + wave] = mx;
+      __syncthreads();
+      mx = L.red[4];
+      for (int k = 1; k < 4; ++k) mx = L.red[4 + k] > mx ? L.red[4 + k] : mx;
+      L.probs[tid] = gmx_expf_tab(sum - mx, L.exptab);
+      __syncthreads();
+      if (tid == 0) {  // valarray::sum(): first element first
+        float t = L.probs[0];
+        for (int i = 1; i < NO; ++i) t += L.probs[i];
+        L.red[0] = t;
+      }
+      __syncthreads();
+      const float p = L.probs[tid] / L.red[0];
+      __syncthreads();
+      L.probs[tid] = p;
+      (B + dv.output + (uint64_t)e * NO)[tid] = p;
+      epoch = epoch + 1 == H ? 0 : epoch + 1;
+      l_epoch = l_epoch + 1 == H ? 0 : l_epoch + 1;
+      // lstm_prediction_context: the first symbol with the largest probability (lstm-model.cpp:25-33)
+      float pm = p;
+      for (int o = 32; o > 0; o >>= 1) {
+        const float other = __shfl_xor(pm, o);
+        pm = other > pm ? other : pm;
+      }
+      if (lane == 0) L.red[4 + wave] = pm;
+      if (tid == 0) L.ired[0] = 0xffffffffu;
+      __syncthreads();
+      pm = L.red[4];
+      for (int k = 1; k < 4; ++k) pm = L.red[4 + k] > pm ? L.red[4 + k] : pm;
+      if (p == pm) atomicMin(&L.ired[0], (uint32_t)tid);
+      __syncthreads();
+      context = pm > 0.0f ? L.ired[0] : 0u;
+    }
+    // ======================= the 8 bit predictions (lstm-model.cpp:34-48) ====================
+    if (tid < 8) {
+      const int k = tid;
+      const int size = 256 >> k, half = size >> 1;
+      const int bot = k == 0 ? 0 : (int)((byte >> (8 - k)) << (8 - k));
+      const int mid = bot + half - 1, top = bot + size - 1;
+      float num = 0.0f;
+      for (int i = mid + 1; i <= top; ++i) num += L.probs[i];
+      float denom = num;
+      for (int i = bot; i <= mid; ++i) denom += L.probs[i];
+      L.nrm[0][k] = num;
+      L.nrm[1][k] = denom;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int k = 0; k < 8; ++k) {  // in bit order: a silent bit leaves the previous prediction
+        const float num = L.nrm[0][k], denom = L.nrm[1][k];
+        uint8_t active = 0;
+        if (denom != 0.0f) {
+          const float p = num / denom;
+          prediction = gmx_logit(p);  // SetPrediction (short-term-memory.cpp:187-191)
+          active = p == 0.5f ? 0 : 1;
+        }
+        pred_s[n * 8 + k] = prediction;
+        act_s[n * 8 + k] = active;
+      }
+      ctx_s[n] = context;
+    }
+    last_byte = byte;
+    if (!a.learn) {
+      __syncthreads();
+      continue;
+    }
+    // ======================= Lstm::Perceive (lstm.cpp:52-93) ================================
+    const uint32_t last_epoch = epoch == 0 ? H - 1 : epoch - 1;
+    const uint32_t old_input = hist[last_epoch];
+    __syncthreads();
+    if (tid == 0) hist[last_epoch] = byte;
+    __syncthreads();
+    if (epoch == 0) {
+      const float alpha = adam_s[bptt_done * 4 + 0], d1 = adam_s[bptt_done * 4 + 1], d2 = adam_s[bptt_done * 4 + 2];
+      for (int ep = H - 1; ep >= 0; --ep) {
+        // output-layer error of this epoch and its pull on the hidden state (lstm.cpp:61-69)
+        {
+          const float o = (B + dv.output + (uint64_t)ep * NO)[tid];
+          L.err[tid] = ((uint32_t)tid == hist[ep]) ? (o - 1.0f) : o;
+          for (int j = tid; j < LIN; j += 256) L.xin[j] = (B + dv.layer_input + (uint64_t)ep * LINP)[j];
+        }
+        __syncthreads();
+        if (tid < NC) {
+          const float* ol = out_layer + ((uint64_t)ep * HID + tid) * NO;
+          float he = L.herr[tid];
+          for (int i = 0; i < NO; ++i) he += ol[i] * L.err[i];
+          L.herr[tid] = he;
+        }
+        __syncthreads();
+        const uint32_t prev_epoch = ep == 0 ? H - 1 : ep - 1;
+        const uint32_t symbol = ep == 0 ? old_input : hist[prev_epoch];
+        // LstmLayer::BackwardPass (lstm-layer.cpp:252-292)
+        if (tid < NC) {
+          const int i = tid;
+          float stored = (B + dv.stored_error)[i], serr = (B + dv.state_error)[i];
+          if (ep == H - 1) {
+            stored = L.herr[i];
+            serr = 0.0f;
+          } else {
+            stored += L.herr[i];
+          }
+          const float ts = (B + dv.tanh_state + (uint64_t)ep * CP)[i];
+          const float og = (B + dv.gate[2].state + (uint64_t)ep * CP)[i];
+          const float in = (B + dv.gate[1].state + (uint64_t)ep * CP)[i];
+          const float fg = (B + dv.gate[0].state + (uint64_t)ep * CP)[i];
+          const float igs = (B + dv.input_gate_state + (uint64_t)ep * CP)[i];
+          const float ls = (B + dv.last_state + (uint64_t)ep * CP)[i];
+          L.act[2][i] = ts * stored * og * (1.0f - og);
+          serr += stored * og * (1.0f - (ts * ts));
+          L.act[1][i] = serr * igs * (1.0f - (in * in));
+          L.act[0][i] = (ls - in) * serr * fg * igs;
+          L.herr[i] = 0.0f;
+          if (ep > 0) {
+            serr *= fg;
+            stored = 0.0f;
+          }
+          (B + dv.stored_error)[i] = stored;
+          (B + dv.state_error)[i] = serr;
+        }
+        if (ep == 0 && update_steps < kUpdateLimit) ++update_steps;
+        __syncthreads();
+        // LstmLayer::BackwardPass(NeuronLayer&) (lstm-layer.cpp:294-355): wave = gate, lane = cell
+        float err = 0.0f, nv = 0.0f;
+        if (wave < 3 && lane < NC) {
+          const GmxLstmGateOff& g = dv.gate[wave];
+          if (ep == H - 1) {
+            (B + g.gamma_u)[lane] = 0.0f;
+            (B + g.beta_u)[lane] = 0.0f;
+            float* up = B + g.update;
+            for (int r = 0; r < W; ++r) up[(uint64_t)r * CP + lane] = 0.0f;
+          }
+          err = L.act[wave][lane];
+          nv = (B + g.norm + (uint64_t)ep * CP)[lane];
+          (B + g.beta_u)[lane] += err;
+          (B + g.gamma_u)[lane] += err * nv;
+          err *= (B + g.gamma)[lane] * (B + g.ivar)[ep];
+          L.nrm[wave][lane] = err * nv;
+        }
+        __syncthreads();
+        if (wave < 3 && lane == 0) {
+          float t = L.nrm[wave][NC - 1];  // expression .sum(): last element first
+          for (int i = NC - 2; i >= 0; --i) t += L.nrm[wave][i];
+          L.red[wave] = t / (float)NC;
+        }
+        __syncthreads();
+        if (wave < 3 && lane < NC) {
+          err -= L.red[wave] * nv;
+          L.act[wave][lane] = err;
+        }
+        __syncthreads();
+        if (wave < 3 && lane < NC) {
+          const GmxLstmGateOff& g = dv.gate[wave];
+          if (ep > 0) {  // through the recurrent weights (transpose_ is a snapshot of them)
+            const float* wr = B + g.weights + (uint64_t)(NO + NI + lane) * CP;
+            float f = 0.0f;
+            for (int j = 0; j < NC; ++j) f += L.act[wave][j] * wr[j];
+            L.fsum[wave][lane] = f;
+          }
+          float* up = B + g.update;
+          for (int j = 0; j < LIN; ++j) up[(uint64_t)(NO + j) * CP + lane] += err * L.xin[j];
+          up[(uint64_t)symbol * CP + lane] += err;
+          if (ep == 0) {  // Adam (lstm-layer.cpp:12-35)
+            const float beta1 = 0.025f, beta2 = 0.9999f, eps = 1e-6f;
+            float* wt = B + g.weights;
+            float* mm = B + g.m;
+            float* vv = B + g.v;
+            for (int r = 0; r < W; ++r) {
+              const uint64_t ix = (uint64_t)r * CP + lane;
+              const float gr = up[ix];
+              float m = mm[ix] * beta1;
+              m += (1.0f - beta1) * gr;
+              float v = vv[ix] * beta2;
+              v += (1.0f - beta2) * gr * gr;
+              mm[ix] = m;
+              vv[ix] = v;
+              wt[ix] -= alpha * ((m / d1) / (sqrtf(v / d2 + eps)));
+            }
+            {
+              const float gr = (B + g.gamma_u)[lane];
+              float m = (B + g.gamma_m)[lane] * beta1;
+              m += (1.0f - beta1) * gr;
+              float v = (B + g.gamma_v)[lane] * beta2;
+              v += (1.0f - beta2) * gr * gr;
+              (B + g.gamma_m)[lane] = m;
+              (B + g.gamma_v)[lane] = v;
+              (B + g.gamma)[lane] -= alpha * ((m / d1) / (sqrtf(v / d2 + eps)));
+            }
+            {
+              const float gr = (B + g.beta_u)[lane];
+              float m = (B + g.beta_m)[lane] * beta1;
+              m += (1.0f - beta1) * gr;
+              float v = (B + g.beta_v)[lane] * beta2;
+              v += (1.0f - beta2) * gr * gr;
+              (B + g.beta_m)[lane] = m;
+              (B + g.beta_v)[lane] = v;
+              (B + g.beta)[lane] -= alpha * ((m / d1) / (sqrtf(v / d2 + eps)));
+            }
+          }
+        }
+        __syncthreads();
+        if (tid < NC) {  // the three gates add to stored_error_ in their order, then the clips
+          float stored = (B + dv.stored_error)[tid];
+          if (ep > 0) {
+            stored += L.fsum[0][tid];
+            stored += L.fsum[1][tid];
+            stored += L.fsum[2][tid];
+          }
+          (B + dv.stored_error)[tid] = clipf(stored);
+          (B + dv.state_error)[tid] = clipf((B + dv.state_error)[tid]);
+          L.herr[tid] = clipf(L.herr[tid]);
+        }
+        __syncthreads();
+      }
+      ++bptt_done;
+    }
+    // the output layer's own step (lstm.cpp:86-92): thread = output symbol
+    {
+      const float o = (B + dv.output + (uint64_t)last_epoch * NO)[tid];
+      const float error = ((uint32_t)tid == byte) ? (o - 1.0f) : o;
+      const float le = kLearningRate * error;
+      const float* src = out_layer + (uint64_t)last_epoch * HID * NO;
+      float* dst = out_layer + (uint64_t)epoch * HID * NO;
+      for (int j = 0; j < HID; ++j) {
+        float v = src[(uint64_t)j * NO + tid];
+        v -= le * L.hid[j];
+        dst[(uint64_t)j * NO + tid] = v;
+      }
+    }
+    __syncthreads();
+  }
+  // state back to the bank
+  if (tid < CP) {
+    (B + dv.hidden)[tid] = L.hid[tid];
+    (B + dv.hidden_error)[tid] = L.herr[tid];
+  }
+  (B + dv.probs)[tid] = L.probs[tid];
+  if (tid == 0) {
+    scal[0] = epoch;
+    scal[1] = l_epoch;
+    scal[2] = update_steps;
+    scal[3] = last_byte;
+    scal[4] = context;
+    scal[5] = __float_as_uint(prediction);
+  }
+}
+
+extern "C" hipError_t gmx_launch_lstm_kernel(const GmxLstmDev* dv, const GmxLstmRunArgs* args, int n_streams,
+                                             hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gmx_lstm_kernel, dim3(n_streams), dim3(256), 0, stream, dv, *args);
+  return hipGetLastError();
+}

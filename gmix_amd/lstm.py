@@ -1,0 +1,121 @@
+"""Host-side handles of the LSTM byte-model banks (gmx_lstm / gmx_lstm_batch of include/gmxmix.h):
+test and bench harness."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import GmxError, check
+
+NC, W, H, NO, HID = 50, 563, 100, 256, 51
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class LstmGroup:
+    def __init__(self, n_streams=1, device=0):
+        self.L = _lib.lib()
+        self.S = int(n_streams)
+        h = C.c_void_p()
+        check(self.L.gmx_lstm_create(C.byref(h), self.S, device), "gmx_lstm_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gmx_lstm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def bank_bytes(self):
+        return self.L.gmx_lstm_bank_bytes(self.h)
+
+    def reset(self):
+        check(self.L.gmx_lstm_reset(self.h), "gmx_lstm_reset")
+
+    def sync(self):
+        check(self.L.gmx_lstm_sync(self.h), "gmx_lstm_sync")
+
+    def set_weights(self, w, stream=0):
+        w = np.ascontiguousarray(w, np.float32)
+        assert w.shape == (3, NC, W)
+        check(self.L.gmx_lstm_set_weights(self.h, stream, _vp(w)), "gmx_lstm_set_weights")
+
+    def get_weights(self, stream=0, output_layer=True):
+        w = np.zeros((3, NC, W), np.float32)
+        o = np.zeros((H, NO, HID), np.float32) if output_layer else None
+        check(self.L.gmx_lstm_get_weights(self.h, stream, _vp(w), _vp(o)), "gmx_lstm_get_weights")
+        return w, o
+
+    def run(self, batch, n_bytes=None, learn=True, timed=False):
+        n = batch.max_bytes if n_bytes is None else n_bytes
+        ms = C.c_float(0)
+        check(self.L.gmx_lstm_run(self.h, batch.h, n, 1 if learn else 0, C.byref(ms) if timed else None),
+              "gmx_lstm_run")
+        return ms.value if timed else None
+
+
+class LstmBatch:
+    def __init__(self, group, max_bytes):
+        self.g = group
+        self.L = group.L
+        self.max_bytes = int(max_bytes)
+        h = C.c_void_p()
+        check(self.L.gmx_lstm_batch_create(C.byref(h), group.h, self.max_bytes), "gmx_lstm_batch_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gmx_lstm_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _view(self, fn, dtype, shape):
+        ptr = fn(self.h)
+        if not ptr:
+            raise GmxError(-2, fn.__name__)
+        n = int(np.prod(shape))
+        buf = (C.c_byte * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    @property
+    def ppm(self):
+        return self._view(self.L.gmx_lstm_batch_ppm, np.float32, (self.g.S, self.max_bytes, 256))
+
+    @property
+    def bytes(self):
+        return self._view(self.L.gmx_lstm_batch_bytes, np.uint8, (self.g.S, self.max_bytes))
+
+    @property
+    def predictions(self):
+        return self._view(self.L.gmx_lstm_batch_predictions, np.float32, (self.g.S, self.max_bytes, 8))
+
+    @property
+    def active(self):
+        return self._view(self.L.gmx_lstm_batch_active, np.uint8, (self.g.S, self.max_bytes, 8))
+
+    @property
+    def contexts(self):
+        return self._view(self.L.gmx_lstm_batch_contexts, np.uint32, (self.g.S, self.max_bytes))
+
+    def upload(self, n_bytes=None):
+        check(self.L.gmx_lstm_batch_upload(self.h, self.max_bytes if n_bytes is None else n_bytes), "gmx_lstm_batch_upload")
+
+    def download(self, n_bytes=None):
+        check(self.L.gmx_lstm_batch_download(self.h, self.max_bytes if n_bytes is None else n_bytes),
+              "gmx_lstm_batch_download")
+
+    def wait(self):
+        check(self.L.gmx_lstm_batch_wait(self.h), "gmx_lstm_batch_wait")

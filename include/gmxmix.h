@@ -238,6 +238,46 @@ int gmx_indirect_import(gmx_indirect* ib, int stream, const void* buf, size_t by
 int gmx_indirect_copy(gmx_indirect* dst, int dst_stream, gmx_indirect* src, int src_stream);
 int gmx_indirect_memory_usage(gmx_indirect* ib, int model, uint64_t* bytes);
 
+/* ==== LSTM byte model ==========================================
+ * The reference's LstmModel (models/lstm-model.h:12-31): Lstm(256, 256, 50, 1, 100, 0.03, 10) over
+ * the PPM byte distribution, predicting the next byte once per byte and the 8 bits from that
+ * distribution; Lstm::Perceive learns the output layer every byte and runs back-propagation
+ * through time + Adam over the last 100 bytes every 100th byte.  Batches are whole bytes. */
+typedef struct gmx_lstm gmx_lstm;
+typedef struct gmx_lstm_batch gmx_lstm_batch;
+
+int gmx_lstm_create(gmx_lstm** out, int n_streams, int device);   /* constructed state, gate weights zero */
+void gmx_lstm_destroy(gmx_lstm* l);
+int gmx_lstm_n_streams(const gmx_lstm* l);
+uint64_t gmx_lstm_bank_bytes(const gmx_lstm* l);
+int gmx_lstm_reset(gmx_lstm* l);
+int gmx_lstm_sync(gmx_lstm* l);
+/* Gate weights in the reference's layout, LongTermMemory::neuron_layer_weights[3][50][563]
+ * (forget gate, input node, output gate): what LstmLayer's constructor draws from rand()
+ * (lstm-layer.cpp:179-194) or a checkpoint holds.  get also returns lstm_output_layer
+ * [100][256][51] (nullable): together the LSTM section of LongTermMemory::WriteToDisk
+ * (long-term-memory.cpp:57-68). */
+int gmx_lstm_set_weights(gmx_lstm* l, int stream, const float* weights);
+int gmx_lstm_get_weights(gmx_lstm* l, int stream, float* weights, float* output_layer);
+
+/* Records per byte: ppm[256] = ShortTermMemory::ppm_predictions at the byte boundary
+ * (mod_ppmd.cpp:1655-1661), the byte itself; results per bit: what LstmModel::Predict left in its
+ * blackboard slot (SetPrediction: the logit; stale when the model stays silent) and whether it was
+ * marked active; per byte: ShortTermMemory::lstm_prediction_context (lstm-model.cpp:25-33). */
+int gmx_lstm_batch_create(gmx_lstm_batch** out, gmx_lstm* l, uint64_t max_bytes);
+void gmx_lstm_batch_destroy(gmx_lstm_batch* b);
+float* gmx_lstm_batch_ppm(gmx_lstm_batch* b);                  /* pinned host [S][max_bytes][256] */
+uint8_t* gmx_lstm_batch_bytes(gmx_lstm_batch* b);              /* [S][max_bytes] */
+const float* gmx_lstm_batch_predictions(gmx_lstm_batch* b);    /* [S][max_bytes][8] */
+const uint8_t* gmx_lstm_batch_active(gmx_lstm_batch* b);       /* [S][max_bytes][8] */
+const uint32_t* gmx_lstm_batch_contexts(gmx_lstm_batch* b);    /* [S][max_bytes] */
+int gmx_lstm_batch_upload(gmx_lstm_batch* b, uint64_t n_bytes);
+int gmx_lstm_batch_download(gmx_lstm_batch* b, uint64_t n_bytes);
+int gmx_lstm_batch_wait(gmx_lstm_batch* b);
+/* LstmModel::Predict x 8 bits (+ LstmModel::Learn when learn != 0) for bytes [0, n_bytes) of every
+ * stream. */
+int gmx_lstm_run(gmx_lstm* l, gmx_lstm_batch* b, uint64_t n_bytes, int learn, float* kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

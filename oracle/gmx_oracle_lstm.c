@@ -400,3 +400,44 @@ uint64_t gmxo_lstm_run_synth(gmxo_lstm* l, uint64_t n_bytes, uint64_t seed, uint
   }
   return h;
 }
+
+/* The synthetic stream as arrays: ppm[n][256], bytes[n]. */
+void gmxo_lstm_synth_fill(uint64_t seed, uint32_t mask, uint64_t n, float* ppm, uint8_t* bytes) {
+  gmx_lstm_synth g;
+  gmx_lstm_synth_init(&g, seed, mask);
+  for (uint64_t i = 0; i < n; ++i) bytes[i] = (uint8_t)gmx_lstm_synth_byte(&g, ppm + i * 256);
+}
+
+/* Same bookkeeping as gmxo_lstm_run_synth on caller-supplied records (what the device kernel
+ * is compared with): pred/act [n][8], ctx [n]; learn == 0 skips LstmModel::Learn. */
+void gmxo_lstm_run(gmxo_lstm* l, uint64_t n_bytes, const float* ppm, const uint8_t* bytes, int learn,
+                   uint32_t* last_byte_io, float* prediction_io, uint32_t* context_io, float* pred_out,
+                   uint8_t* act_out, uint32_t* ctx_out) {
+  int recent_bits = 1, new_bit = 0;
+  uint32_t last_byte = *last_byte_io, context = *context_io;
+  float prediction = *prediction_io;
+  for (uint64_t n = 0; n < n_bytes; ++n) {
+    for (int k = 0; k < 8; ++k) {
+      uint8_t act = (uint8_t)gmxo_lstm_model_predict(l, recent_bits, last_byte, new_bit, ppm + n * 256, &prediction,
+                                                     &context, 0);
+      pred_out[n * 8 + k] = prediction;
+      act_out[n * 8 + k] = act;
+      if (k == 0) ctx_out[n] = context;
+      new_bit = (int)((bytes[n] >> (7 - k)) & 1u);
+      if (learn) gmxo_lstm_model_learn(l, recent_bits, new_bit);
+      recent_bits += recent_bits + new_bit;
+      if (recent_bits >= 256) {
+        last_byte = (uint32_t)(recent_bits - 256);
+        recent_bits = 1;
+      }
+    }
+  }
+  *last_byte_io = last_byte;
+  *prediction_io = prediction;
+  *context_io = context;
+}
+
+void gmxo_lstm_get_output_layer(const gmxo_lstm* l, float* out /* [H][NO][HID] */) {
+  memcpy(out, l->out_layer, (size_t)H * NO * HID * 4);
+}
+uint64_t gmxo_lstm_update_steps(const gmxo_lstm* l) { return l->update_steps; }

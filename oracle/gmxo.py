@@ -344,6 +344,12 @@ def _lstm_lib():
         L.gmxo_lstm_run_synth.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p,
                                           C.c_void_p, C.c_void_p]
         L.gmxo_srand.argtypes = [C.c_uint]
+        L.gmxo_lstm_synth_fill.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.gmxo_lstm_run.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint32),
+                                    C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gmxo_lstm_get_output_layer.argtypes = [C.c_void_p, C.c_void_p]
+        L.gmxo_lstm_update_steps.restype = C.c_uint64
+        L.gmxo_lstm_update_steps.argtypes = [C.c_void_p]
         L._lstm_ready = True
     return L
 
@@ -364,6 +370,30 @@ class LstmModel:
 
     def weights_hash(self, with_output_layer=False):
         return int(self.L.gmxo_lstm_weights_hash(self.h, 1 if with_output_layer else 0))
+
+    def weights(self):
+        w = np.zeros((3, 50, 563), np.float32)
+        self.L.gmxo_lstm_get_weights(self.h, _p(w))
+        return w
+
+    def output_layer(self):
+        o = np.zeros((100, 256, 51), np.float32)
+        self.L.gmxo_lstm_get_output_layer(self.h, _p(o))
+        return o
+
+    def run(self, ppm, data, learn=True):
+        """Whole bytes through LstmModel::Predict x 8 (+ Learn): (pred[n,8], active[n,8], ctx[n])."""
+        ppm = np.ascontiguousarray(ppm, np.float32)
+        data = np.ascontiguousarray(data, np.uint8)
+        n = len(data)
+        pred = np.zeros((n, 8), np.float32)
+        act = np.zeros((n, 8), np.uint8)
+        ctx = np.zeros(n, np.uint32)
+        if not hasattr(self, "_lb"):
+            self._lb, self._pr, self._cx = C.c_uint32(0), C.c_float(0), C.c_uint32(0)
+        self.L.gmxo_lstm_run(self.h, n, _p(ppm), _p(data), 1 if learn else 0, C.byref(self._lb), C.byref(self._pr),
+                             C.byref(self._cx), _p(pred), _p(act), _p(ctx))
+        return pred, act, ctx
 
     def run_synth(self, n_bytes, seed=0, mask=255, dump=0):
         """Drive the model with oracle/gmx_lstm_synth.h like the reference harness does; returns
@@ -399,3 +429,12 @@ def read_lstm_dump(path):
     assert o + 12 + 1024 == len(raw)
     return dict(N=N, D=D, init_weights_hash=hw, pred=pred, active=act, ctx=ctx, h64=h, long_hash=hl, usage=usage,
                 short_size=short_size, short_hash=hs, top=top, mid=mid, bot=bot, probs=probs)
+
+
+def lstm_synth(n_bytes, seed=0, mask=255):
+    """(ppm[n,256] f32, bytes[n] u8) of oracle/gmx_lstm_synth.h."""
+    L = _lstm_lib()
+    ppm = np.zeros((n_bytes, 256), np.float32)
+    data = np.zeros(n_bytes, np.uint8)
+    L.gmxo_lstm_synth_fill(seed, mask, n_bytes, _p(ppm), _p(data))
+    return ppm, data

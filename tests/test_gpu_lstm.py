@@ -1,0 +1,77 @@
+"""The LSTM byte-model banks (gmx_lstm.hip behind gmx_lstm_* of include/gmxmix.h) against the
+oracle restatement, which tests/test_oracle_lstm.py pins to the real reference LstmModel: every
+bit prediction and active flag, lstm_prediction_context, and the learned weights after backward
+passes -- bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def u32(x):
+    return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+def run_gpu(gpu, g, streams, chunk, learn=True):
+    S, N = len(streams), len(streams[0][1])
+    b = gpu.LstmBatch(g, chunk)
+    P = np.zeros((S, N, 8), np.float32)
+    A = np.zeros((S, N, 8), np.uint8)
+    Cx = np.zeros((S, N), np.uint32)
+    for n0 in range(0, N, chunk):
+        n = min(chunk, N - n0)
+        for s, (ppm, data) in enumerate(streams):
+            b.ppm[s, :n] = ppm[n0:n0 + n]
+            b.bytes[s, :n] = data[n0:n0 + n]
+        b.upload(n)
+        g.run(b, n, learn=learn)
+        b.download(n)
+        b.wait()
+        P[:, n0:n0 + n] = b.predictions[:, :n]
+        A[:, n0:n0 + n] = b.active[:, :n]
+        Cx[:, n0:n0 + n] = b.contexts[:, :n]
+    b.close()
+    return P, A, Cx
+
+
+def test_lstm_kernel_equals_oracle_through_backward_passes(gpu, oracle):
+    S, N = 3, 450                       # four backward passes + Adam steps, launches that split them
+    refs, streams = [], []
+    for s in range(S):
+        m = oracle.LstmModel()          # srand(0xDEADBEEF) + the reference's constructor chain
+        ppm, data = oracle.lstm_synth(N, seed=11 + s, mask=15 if s == 1 else 255)
+        refs.append((m, m.weights()) + m.run(ppm, data))
+        streams.append((ppm, data))
+    g = gpu.LstmGroup(S)
+    for s in range(S):
+        g.set_weights(refs[s][1], stream=s)
+    P, A, Cx = run_gpu(gpu, g, streams, chunk=170)
+    for s in range(S):
+        m, _, pred, act, ctx = refs[s]
+        bad = np.argwhere(u32(P[s]) != u32(pred))
+        assert len(bad) == 0, (s, bad[:4], P[s][tuple(bad[0])], pred[tuple(bad[0])])
+        assert np.array_equal(A[s], act) and np.array_equal(Cx[s], ctx)
+        w, o = g.get_weights(s)
+        assert np.array_equal(u32(w), u32(m.weights())), s
+        assert np.array_equal(u32(o), u32(m.output_layer())), s
+    g.close()
+
+
+def test_lstm_generation_mode_and_restart(gpu, oracle):
+    """Predict without Learn (runner-utils.cpp:199-209) changes nothing but the recurrent state;
+    a second group fed the same weights reproduces the first."""
+    N = 230
+    m = oracle.LstmModel()
+    w0 = m.weights()
+    ppm, data = oracle.lstm_synth(N, seed=5, mask=63)
+    p1, a1, c1 = m.run(ppm[:130], data[:130])
+    p2, a2, c2 = m.run(ppm[130:], data[130:], learn=False)
+    g = gpu.LstmGroup(1)
+    g.set_weights(w0)
+    P, A, Cx = run_gpu(gpu, g, [(ppm[:130], data[:130])], chunk=130)
+    P2, A2, Cx2 = run_gpu(gpu, g, [(ppm[130:], data[130:])], chunk=100, learn=False)
+    assert np.array_equal(u32(P[0]), u32(p1)) and np.array_equal(u32(P2[0]), u32(p2))
+    assert np.array_equal(A2[0], a2) and np.array_equal(Cx2[0], c2)
+    w, o = g.get_weights(0)
+    assert np.array_equal(u32(w), u32(m.weights())) and np.array_equal(u32(o), u32(m.output_layer()))
+    g.close()
