@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Auxiliary bench line for the LSTM byte model: S streams x N bytes
+per launch, Predict x 8 bits + Learn (backward pass every 100th byte).
+  python scripts/bench_lstm.py [--streams S --bytes N --steps K]"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=1024)
+    ap.add_argument("--bytes", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-sample-bytes", type=int, default=20000)
+    args = ap.parse_args()
+    import gmix_amd
+    from oracle import gmxo
+    S, N = args.streams, args.bytes
+    g = gmix_amd.LstmGroup(S)
+    w = gmxo.LstmModel().weights()
+    for s in range(S):
+        g.set_weights(w, stream=s)
+    b = gmix_amd.LstmBatch(g, N)
+    ppm, data = gmxo.lstm_synth(N, seed=1, mask=63)
+    rng = np.random.default_rng(0)
+    for s in range(S):   # same distributions, different byte streams
+        b.ppm[s] = ppm
+        b.bytes[s] = np.roll(data, int(rng.integers(0, N)))
+    b.upload(N)
+    for _ in range(args.warmup):
+        g.run(b, N, learn=True)
+    g.sync()
+    ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ms.append(g.run(b, N, learn=True, timed=True))
+    g.sync()
+    el = time.perf_counter() - t0
+    avg = sum(ms) / len(ms)
+    # algorithmic HBM bytes per stream-byte: gate weights read once per forward (3 x 50 x 308 x 4),
+    # the output layer read and its next ring slot written (2 x 256 x 51 x 4), the records; per
+    # backward epoch (one per byte on average): 3 gates' accumulators read+written (2 x 3 x 50 x 308 x 4),
+    # the output layer of the epoch read again (256 x 51 x 4), Adam amortised (3 x 4 x 2 x 563 x 50 x 4 / 100)
+    bpb = 3 * 50 * 308 * 4 + 2 * 256 * 51 * 4 + 1024 + 2 * 3 * 50 * 308 * 4 + 256 * 51 * 4 + 3 * 4 * 2 * 563 * 50 * 4 // 100
+    out = {"metric": "LSTM byte-model bytes/sec (Predict x 8 bits + Learn, backward pass every 100th byte)",
+           "value": S * N * args.steps / el, "unit": "bytes/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "LstmModel (Lstm(256,256,50,1,100,0.03,10))", "streams": S, "bytes_per_stream_per_step": N,
+                      "bank_bytes_per_stream": g.bank_bytes, "bits_per_s": S * N * 8 * args.steps / el},
+           "roofline": {"bound": "hbm", "achieved": bpb * S * N / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": bpb * S * N / (avg * 1e-3) / 1e9 / 8000.0, "traffic": None, "kernel": "gmx_lstm_kernel",
+                        "kernel_ms_avg": avg, "algorithmic_bytes_per_byte": bpb}}
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_lstm_harness")
+    if os.path.exists(exe):
+        n = args.cpu_sample_bytes
+        t1 = time.perf_counter()
+        subprocess.run([exe, "--bytes", str(n), "--seed", "1", "--mask", "63", "--out", "/tmp/_lstm_cpu.bin"], check=True,
+                       stdout=subprocess.DEVNULL)
+        dt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": n / dt, "unit": "bytes/s", "cores": 1, "kind": "reference",
+                               "sample": f"{n} bytes through the reference's own LstmModel (strict -O2 harness), 1 thread of {os.cpu_count()}"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
