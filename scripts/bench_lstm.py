@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-sample-bytes", type=int, default=20000)
+    ap.add_argument("--no-learn", action="store_true", help="Predict only (generation mode)")
     args = ap.parse_args()
     import gmix_amd
     from oracle import gmxo
@@ -38,12 +39,12 @@ def main():
         b.bytes[s] = np.roll(data, int(rng.integers(0, N)))
     b.upload(N)
     for _ in range(args.warmup):
-        g.run(b, N, learn=True)
+        g.run(b, N, learn=not args.no_learn)
     g.sync()
     ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ms.append(g.run(b, N, learn=True, timed=True))
+        ms.append(g.run(b, N, learn=not args.no_learn, timed=True))
     g.sync()
     el = time.perf_counter() - t0
     avg = sum(ms) / len(ms)
