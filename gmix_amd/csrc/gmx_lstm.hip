@@ -13,8 +13,12 @@
 //   * in the backward pass the 50 hidden-error chains (256 steps each), the three gates, and the
 //     563 x 50 independent accumulators / Adam updates of each gate;
 //   * the 8 bit predictions of a byte (their ranges follow from the byte), one lane each.
-// This is the first, correctness-first version of this path: no LDS weight staging, barriers
-// between phases, scalar loads.  oracle/gmx_oracle_lstm.c is the line-by-line specification.
+// The chains are latency-bound if their operands are fetched as they go (hipcc waits for every
+// small batch of loads before the adds that use it: 58 us per forward pass), so every chain first
+// issues the loads of a long stretch (up to 104 weights) and then runs its adds on registers.
+// (Keeping the gradient accumulators of a backward pass in registers with 1024 threads was tried:
+// it removes half of the HBM traffic but leaves one workgroup per CU, and this kernel lives on
+// the number of streams in flight.)  oracle/gmx_oracle_lstm.c is the line-by-line specification.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -92,7 +96,16 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
         const GmxLstmGateOff& g = dv.gate[wave];
         const float* w = B + g.weights;
         float f = w[(uint64_t)last_byte * CP + lane];
-        for (int j = 0; j < LIN; ++j) f += L.xin[j] * w[(uint64_t)(NO + j) * CP + lane];
+        constexpr int kStretch = 104;  // 3 x 104 >= 307
+#pragma unroll 1
+        for (int j0 = 0; j0 < LIN; j0 += kStretch) {
+          float wv[kStretch];
+#pragma unroll
+          for (int u = 0; u < kStretch; ++u) wv[u] = w[(uint64_t)(NO + (j0 + u < LIN ? j0 + u : LIN - 1)) * CP + lane];
+#pragma unroll
+          for (int u = 0; u < kStretch; ++u)
+            if (j0 + u < LIN) f += L.xin[j0 + u] * wv[u];
+        }
         L.nrm[wave][lane] = f;
       }
       __syncthreads();
@@ -129,7 +142,13 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       // output layer + softmax (lstm.cpp:106-118): thread = output symbol
       const float* ol = out_layer + (uint64_t)e * HID * NO;
       float sum = 0.0f;
-      for (int j = 0; j < HID; ++j) sum += L.hid[j] * ol[(uint64_t)j * NO + tid];
+      {
+        float ov[HID];
+#pragma unroll
+        for (int j = 0; j < HID; ++j) ov[j] = ol[(uint64_t)j * NO + tid];
+#pragma unroll
+        for (int j = 0; j < HID; ++j) sum += L.hid[j] * ov[j];
+      }
       // max_out = max(0, every sum): order does not matter for a maximum
       float mx = sum > 0.0f ? sum : 0.0f;
       for (int o = 32; o > 0; o >>= 1) {
@@ -221,7 +240,19 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
         if (tid < NC) {
           const float* ol = out_layer + ((uint64_t)ep * HID + tid) * NO;
           float he = L.herr[tid];
-          for (int i = 0; i < NO; ++i) he += ol[i] * L.err[i];
+#pragma unroll 1
+          for (int i0 = 0; i0 < NO; i0 += 128) {
+            float4 ov[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) ov[u] = *(const float4*)(ol + i0 + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+              he += ov[u].x * L.err[i0 + 4 * u + 0];
+              he += ov[u].y * L.err[i0 + 4 * u + 1];
+              he += ov[u].z * L.err[i0 + 4 * u + 2];
+              he += ov[u].w * L.err[i0 + 4 * u + 3];
+            }
+          }
           L.herr[tid] = he;
         }
         __syncthreads();
@@ -291,27 +322,52 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
           if (ep > 0) {  // through the recurrent weights (transpose_ is a snapshot of them)
             const float* wr = B + g.weights + (uint64_t)(NO + NI + lane) * CP;
             float f = 0.0f;
-            for (int j = 0; j < NC; ++j) f += L.act[wave][j] * wr[j];
+            float rv[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) rv[j] = wr[j];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) f += L.act[wave][j] * rv[j];
             L.fsum[wave][lane] = f;
           }
           float* up = B + g.update;
-          for (int j = 0; j < LIN; ++j) up[(uint64_t)(NO + j) * CP + lane] += err * L.xin[j];
+#pragma unroll 1
+          for (int j0 = 0; j0 < LIN; j0 += 64) {
+            float uv[64];
+#pragma unroll
+            for (int u = 0; u < 64; ++u) uv[u] = up[(uint64_t)(NO + (j0 + u < LIN ? j0 + u : LIN - 1)) * CP + lane];
+#pragma unroll
+            for (int u = 0; u < 64; ++u)
+              if (j0 + u < LIN) up[(uint64_t)(NO + j0 + u) * CP + lane] = uv[u] + err * L.xin[j0 + u];
+          }
           up[(uint64_t)symbol * CP + lane] += err;
           if (ep == 0) {  // Adam (lstm-layer.cpp:12-35)
             const float beta1 = 0.025f, beta2 = 0.9999f, eps = 1e-6f;
             float* wt = B + g.weights;
             float* mm = B + g.m;
             float* vv = B + g.v;
-            for (int r = 0; r < W; ++r) {
-              const uint64_t ix = (uint64_t)r * CP + lane;
-              const float gr = up[ix];
-              float m = mm[ix] * beta1;
-              m += (1.0f - beta1) * gr;
-              float v = vv[ix] * beta2;
-              v += (1.0f - beta2) * gr * gr;
-              mm[ix] = m;
-              vv[ix] = v;
-              wt[ix] -= alpha * ((m / d1) / (sqrtf(v / d2 + eps)));
+#pragma unroll 1
+            for (int r0 = 0; r0 < W; r0 += 16) {
+              float gr[16], m[16], v[16], wq[16];
+#pragma unroll
+              for (int u = 0; u < 16; ++u) {
+                const uint64_t ix = (uint64_t)(r0 + u < W ? r0 + u : W - 1) * CP + lane;
+                gr[u] = up[ix];
+                m[u] = mm[ix];
+                v[u] = vv[ix];
+                wq[u] = wt[ix];
+              }
+#pragma unroll
+              for (int u = 0; u < 16; ++u) {
+                if (r0 + u >= W) continue;
+                const uint64_t ix = (uint64_t)(r0 + u) * CP + lane;
+                float mn = m[u] * beta1;
+                mn += (1.0f - beta1) * gr[u];
+                float vn = v[u] * beta2;
+                vn += (1.0f - beta2) * gr[u] * gr[u];
+                mm[ix] = mn;
+                vv[ix] = vn;
+                wt[ix] = wq[u] - alpha * ((mn / d1) / (sqrtf(vn / d2 + eps)));
+              }
             }
             {
               const float gr = (B + g.gamma_u)[lane];
@@ -358,11 +414,11 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       const float le = kLearningRate * error;
       const float* src = out_layer + (uint64_t)last_epoch * HID * NO;
       float* dst = out_layer + (uint64_t)epoch * HID * NO;
-      for (int j = 0; j < HID; ++j) {
-        float v = src[(uint64_t)j * NO + tid];
-        v -= le * L.hid[j];
-        dst[(uint64_t)j * NO + tid] = v;
-      }
+      float sv[HID];
+#pragma unroll
+      for (int j = 0; j < HID; ++j) sv[j] = src[(uint64_t)j * NO + tid];
+#pragma unroll
+      for (int j = 0; j < HID; ++j) dst[(uint64_t)j * NO + tid] = sv[j] - le * L.hid[j];
     }
     __syncthreads();
   }
