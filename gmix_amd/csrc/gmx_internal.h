@@ -143,6 +143,7 @@ struct GmxIndRunArgs {
 #define GMX_L_W 563       // one-hot symbol column (256) + layer input (307)
 #define GMX_L_HID 51
 #define GMX_L_CP 64
+#define GMX_L_HP 100
 
 struct GmxLstmGateOff {   // float offsets inside a bank
   uint64_t weights, update, m, v;                 // [W][CP]   (row = input index, column = cell)
@@ -158,6 +159,8 @@ struct GmxLstmDev {
   uint64_t tanh_state, input_gate_state, last_state;  // [H][CP]
   uint64_t hidden, hidden_error;                  // [CP]
   uint64_t layer_input;                           // [H][LINP]
+  uint64_t lin_t;                                 // [LIN][GMX_L_HP]: the same, input-major (one row = one input over the epochs)
+  uint64_t errs;                                  // [3][H][CP]: the gates' final errors of a backward pass
   uint64_t output;                                // [H][NO]
   uint64_t input_history;                         // u32 [H]
   uint64_t probs;                                 // [NO]  LstmModel::probs_

@@ -16,14 +16,31 @@
 // The chains are latency-bound if their operands are fetched as they go (hipcc waits for every
 // small batch of loads before the adds that use it: 58 us per forward pass), so every chain first
 // issues the loads of a long stretch (up to 104 weights) and then runs its adds on registers.
-// (Keeping the gradient accumulators of a backward pass in registers with 1024 threads was tried:
-// it removes half of the HBM traffic but leaves one workgroup per CU, and this kernel lives on
-// the number of streams in flight.)  oracle/gmx_oracle_lstm.c is the line-by-line specification.
+// At thousands of streams the kernel is HBM-bound, and half of its traffic used to be the gradient
+// accumulators (NeuronLayer::update_, read and written once per epoch of a backward pass).  They
+// are now never stored: the epochs only record each gate's final error vector, and after the last
+// epoch every accumulator is formed in a register -- update[cell][256+r] = sum over the epochs, in
+// the reference's order, of error[epoch][cell] * input[epoch][r], the layer inputs being kept
+// input-major for this -- and consumed by Adam on the spot.  The one-hot symbol columns, of which
+// an epoch touches one row, stay in HBM.  oracle/gmx_oracle_lstm.c is the line-by-line
+// specification.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "gmx_internal.h"
 #include "gmx_math.h"
+
+// Loads a chain issues before its adds (GMX_LSTM_STRETCH weights, GMX_LSTM_Q float4s) against
+// workgroups per CU (GMX_LSTM_BLOCKS): shorter stretches cost latency per byte, fewer registers
+// let more streams run at once.  Measured at 2048 streams every setting between 2 and 4 workgroups
+// per CU lands on the same throughput (the kernel is HBM-bound there); the longer stretches win at
+// few streams.
+#ifndef GMX_LSTM_STRETCH
+#define GMX_LSTM_STRETCH 104
+#define GMX_LSTM_Q 32
+#define GMX_LSTM_BLOCKS 2
+#define GMX_LSTM_ADAM 16
+#endif
 
 namespace {
 
@@ -50,7 +67,7 @@ __device__ __forceinline__ float clipf(float a) { return a < -kClip ? -kClip : (
 
 }  // namespace
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, GMX_LSTM_BLOCKS)
 gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
   __shared__ Lds L;
   const GmxLstmDev& dv = *dvp;
@@ -90,13 +107,16 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       if (tid == 0) L.xin[LIN - 1] = 1.0f;
       if (tid < NC) (B + dv.last_state + (uint64_t)le * CP)[tid] = (B + dv.state)[tid];  // lstm-layer.cpp:200
       __syncthreads();
-      for (int j = tid; j < LIN; j += 256) lin[j] = L.xin[j];
+      for (int j = tid; j < LIN; j += 256) {
+        lin[j] = L.xin[j];
+        (B + dv.lin_t)[(uint64_t)j * GMX_L_HP + e] = L.xin[j];
+      }
       // LstmLayer::ForwardPass(NeuronLayer&) (lstm-layer.cpp:221-241): wave = gate, lane = cell
       if (wave < 3 && lane < NC) {
         const GmxLstmGateOff& g = dv.gate[wave];
         const float* w = B + g.weights;
         float f = w[(uint64_t)last_byte * CP + lane];
-        constexpr int kStretch = 104;  // 3 x 104 >= 307
+        constexpr int kStretch = GMX_LSTM_STRETCH;
 #pragma unroll 1
         for (int j0 = 0; j0 < LIN; j0 += kStretch) {
           float wv[kStretch];
@@ -198,21 +218,19 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       for (int i = mid + 1; i <= top; ++i) num += L.probs[i];
       float denom = num;
       for (int i = bot; i <= mid; ++i) denom += L.probs[i];
-      L.nrm[0][k] = num;
-      L.nrm[1][k] = denom;
+      // SetPrediction (short-term-memory.cpp:187-191); a silent bit (denom == 0) keeps the slot
+      const float p = num / denom;
+      L.nrm[0][k] = gmx_logit(p);
+      L.ired[1 + 0] = 0;
+      L.nrm[1][k] = denom != 0.0f ? (p == 0.5f ? 1.0f : 2.0f) : 0.0f;  // 0 silent, 1 inactive, 2 active
     }
     __syncthreads();
     if (tid == 0) {
       for (int k = 0; k < 8; ++k) {  // in bit order: a silent bit leaves the previous prediction
-        const float num = L.nrm[0][k], denom = L.nrm[1][k];
-        uint8_t active = 0;
-        if (denom != 0.0f) {
-          const float p = num / denom;
-          prediction = gmx_logit(p);  // SetPrediction (short-term-memory.cpp:187-191)
-          active = p == 0.5f ? 0 : 1;
-        }
+        const float st = L.nrm[1][k];
+        if (st != 0.0f) prediction = L.nrm[0][k];
         pred_s[n * 8 + k] = prediction;
-        act_s[n * 8 + k] = active;
+        act_s[n * 8 + k] = st == 2.0f ? 1 : 0;
       }
       ctx_s[n] = context;
     }
@@ -241,12 +259,12 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
           const float* ol = out_layer + ((uint64_t)ep * HID + tid) * NO;
           float he = L.herr[tid];
 #pragma unroll 1
-          for (int i0 = 0; i0 < NO; i0 += 128) {
-            float4 ov[32];
+          for (int i0 = 0; i0 < NO; i0 += 4 * GMX_LSTM_Q) {
+            float4 ov[GMX_LSTM_Q];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) ov[u] = *(const float4*)(ol + i0 + 4 * u);
+            for (int u = 0; u < GMX_LSTM_Q; ++u) ov[u] = *(const float4*)(ol + i0 + 4 * u);
 #pragma unroll
-            for (int u = 0; u < 32; ++u) {
+            for (int u = 0; u < GMX_LSTM_Q; ++u) {
               he += ov[u].x * L.err[i0 + 4 * u + 0];
               he += ov[u].y * L.err[i0 + 4 * u + 1];
               he += ov[u].z * L.err[i0 + 4 * u + 2];
@@ -296,7 +314,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
             (B + g.gamma_u)[lane] = 0.0f;
             (B + g.beta_u)[lane] = 0.0f;
             float* up = B + g.update;
-            for (int r = 0; r < W; ++r) up[(uint64_t)r * CP + lane] = 0.0f;
+            for (int r = 0; r < NO; ++r) up[(uint64_t)r * CP + lane] = 0.0f;  // the symbol columns
           }
           err = L.act[wave][lane];
           nv = (B + g.norm + (uint64_t)ep * CP)[lane];
@@ -329,67 +347,8 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
             for (int j = 0; j < NC; ++j) f += L.act[wave][j] * rv[j];
             L.fsum[wave][lane] = f;
           }
-          float* up = B + g.update;
-#pragma unroll 1
-          for (int j0 = 0; j0 < LIN; j0 += 64) {
-            float uv[64];
-#pragma unroll
-            for (int u = 0; u < 64; ++u) uv[u] = up[(uint64_t)(NO + (j0 + u < LIN ? j0 + u : LIN - 1)) * CP + lane];
-#pragma unroll
-            for (int u = 0; u < 64; ++u)
-              if (j0 + u < LIN) up[(uint64_t)(NO + j0 + u) * CP + lane] = uv[u] + err * L.xin[j0 + u];
-          }
-          up[(uint64_t)symbol * CP + lane] += err;
-          if (ep == 0) {  // Adam (lstm-layer.cpp:12-35)
-            const float beta1 = 0.025f, beta2 = 0.9999f, eps = 1e-6f;
-            float* wt = B + g.weights;
-            float* mm = B + g.m;
-            float* vv = B + g.v;
-#pragma unroll 1
-            for (int r0 = 0; r0 < W; r0 += 16) {
-              float gr[16], m[16], v[16], wq[16];
-#pragma unroll
-              for (int u = 0; u < 16; ++u) {
-                const uint64_t ix = (uint64_t)(r0 + u < W ? r0 + u : W - 1) * CP + lane;
-                gr[u] = up[ix];
-                m[u] = mm[ix];
-                v[u] = vv[ix];
-                wq[u] = wt[ix];
-              }
-#pragma unroll
-              for (int u = 0; u < 16; ++u) {
-                if (r0 + u >= W) continue;
-                const uint64_t ix = (uint64_t)(r0 + u) * CP + lane;
-                float mn = m[u] * beta1;
-                mn += (1.0f - beta1) * gr[u];
-                float vn = v[u] * beta2;
-                vn += (1.0f - beta2) * gr[u] * gr[u];
-                mm[ix] = mn;
-                vv[ix] = vn;
-                wt[ix] = wq[u] - alpha * ((mn / d1) / (sqrtf(vn / d2 + eps)));
-              }
-            }
-            {
-              const float gr = (B + g.gamma_u)[lane];
-              float m = (B + g.gamma_m)[lane] * beta1;
-              m += (1.0f - beta1) * gr;
-              float v = (B + g.gamma_v)[lane] * beta2;
-              v += (1.0f - beta2) * gr * gr;
-              (B + g.gamma_m)[lane] = m;
-              (B + g.gamma_v)[lane] = v;
-              (B + g.gamma)[lane] -= alpha * ((m / d1) / (sqrtf(v / d2 + eps)));
-            }
-            {
-              const float gr = (B + g.beta_u)[lane];
-              float m = (B + g.beta_m)[lane] * beta1;
-              m += (1.0f - beta1) * gr;
-              float v = (B + g.beta_v)[lane] * beta2;
-              v += (1.0f - beta2) * gr * gr;
-              (B + g.beta_m)[lane] = m;
-              (B + g.beta_v)[lane] = v;
-              (B + g.beta)[lane] -= alpha * ((m / d1) / (sqrtf(v / d2 + eps)));
-            }
-          }
+          (B + g.update)[(uint64_t)symbol * CP + lane] += err;       // lstm-layer.cpp:342
+          (B + dv.errs + ((uint64_t)wave * H + ep) * CP)[lane] = err;  // for the deferred accumulation
         }
         __syncthreads();
         if (tid < NC) {  // the three gates add to stored_error_ in their order, then the clips
@@ -405,6 +364,62 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
         }
         __syncthreads();
       }
+      __syncthreads();
+      // update_[cell][256 + r] (lstm-layer.cpp:341) formed in a register -- the epochs' products
+      // added in the reference's order, 99 down to 0 -- and handed to Adam (lstm-layer.cpp:12-35)
+      // right away; then the symbol columns and the layer-norm parameters.
+      {
+        const float beta1 = 0.025f, beta2 = 0.9999f, eps = 1e-6f;
+        auto adam1 = [&](float gr, float* mp, float* vp, float* wp) {
+          float m = *mp * beta1;
+          m += (1.0f - beta1) * gr;
+          float v = *vp * beta2;
+          v += (1.0f - beta2) * gr * gr;
+          *mp = m;
+          *vp = v;
+          *wp -= alpha * ((m / d1) / (sqrtf(v / d2 + eps)));
+        };
+        const int cl = lane < NC ? lane : 0;  // idle lanes shadow cell 0 and do not store
+#pragma unroll 1
+        for (int g = 0; g < 3; ++g) {
+          const GmxLstmGateOff& go = dv.gate[g];
+          float ereg[H];
+#pragma unroll
+          for (int ep = 0; ep < H; ++ep) ereg[ep] = (B + dv.errs + ((uint64_t)g * H + ep) * CP)[cl];
+#pragma unroll 1
+          for (int r = wave; r < LIN; r += 4) {
+            const float4* xr = (const float4*)(B + dv.lin_t + (uint64_t)r * GMX_L_HP);
+            float4 xv[H / 4];
+#pragma unroll
+            for (int q = 0; q < H / 4; ++q) xv[q] = xr[q];
+            float acc = 0.0f;
+#pragma unroll
+            for (int q = H / 4 - 1; q >= 0; --q) {
+              acc += ereg[4 * q + 3] * xv[q].w;
+              acc += ereg[4 * q + 2] * xv[q].z;
+              acc += ereg[4 * q + 1] * xv[q].y;
+              acc += ereg[4 * q + 0] * xv[q].x;
+            }
+            if (lane < NC) {
+              const uint64_t ix = (uint64_t)(NO + r) * CP + lane;
+              adam1(acc, B + go.m + ix, B + go.v + ix, B + go.weights + ix);
+            }
+          }
+          if (lane < NC) {
+#pragma unroll 4
+            for (int r = wave; r < NO; r += 4) {
+              const uint64_t ix = (uint64_t)r * CP + lane;
+              adam1((B + go.update)[ix], B + go.m + ix, B + go.v + ix, B + go.weights + ix);
+            }
+          }
+        }
+        if (wave < 3 && lane < NC) {
+          const GmxLstmGateOff& go = dv.gate[wave];
+          adam1((B + go.gamma_u)[lane], B + go.gamma_m + lane, B + go.gamma_v + lane, B + go.gamma + lane);
+          adam1((B + go.beta_u)[lane], B + go.beta_m + lane, B + go.beta_v + lane, B + go.beta + lane);
+        }
+      }
+      __syncthreads();
       ++bptt_done;
     }
     // the output layer's own step (lstm.cpp:86-92): thread = output symbol
