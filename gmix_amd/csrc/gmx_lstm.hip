@@ -32,14 +32,14 @@
 
 // Loads a chain issues before its adds (GMX_LSTM_STRETCH weights, GMX_LSTM_Q float4s) against
 // workgroups per CU (GMX_LSTM_BLOCKS): shorter stretches cost latency per byte, fewer registers
-// let more streams run at once.  Measured at 2048 streams every setting between 2 and 4 workgroups
-// per CU lands on the same throughput (the kernel is HBM-bound there); the longer stretches win at
-// few streams.
+// let more streams run at once.  Measured at 4096 streams: 2 workgroups per CU (stretches of 104)
+// 7.9e6 bytes/s, 3 per CU (77) 8.5e6, 4 per CU (52) 8.4e6; the longer stretches win at few streams.
 #ifndef GMX_LSTM_STRETCH
-#define GMX_LSTM_STRETCH 104
-#define GMX_LSTM_Q 32
-#define GMX_LSTM_BLOCKS 2
-#define GMX_LSTM_ADAM 16
+#define GMX_LSTM_STRETCH 77
+#define GMX_LSTM_Q 16
+#define GMX_LSTM_BLOCKS 3
+#define GMX_LSTM_ADAM 12
+#define GMX_LSTM_XPARTS 5   /* 1 or 5: parts the 100 epochs of a row are fetched in */
 #endif
 
 namespace {
@@ -389,16 +389,21 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
 #pragma unroll 1
           for (int r = wave; r < LIN; r += 4) {
             const float4* xr = (const float4*)(B + dv.lin_t + (uint64_t)r * GMX_L_HP);
-            float4 xv[H / 4];
-#pragma unroll
-            for (int q = 0; q < H / 4; ++q) xv[q] = xr[q];
             float acc = 0.0f;
 #pragma unroll
-            for (int q = H / 4 - 1; q >= 0; --q) {
-              acc += ereg[4 * q + 3] * xv[q].w;
-              acc += ereg[4 * q + 2] * xv[q].z;
-              acc += ereg[4 * q + 1] * xv[q].y;
-              acc += ereg[4 * q + 0] * xv[q].x;
+            for (int hq = GMX_LSTM_XPARTS - 1; hq >= 0; --hq) {  // epochs 99 down to 0, a part at a time
+              constexpr int kPart = H / 4 / GMX_LSTM_XPARTS;
+              float4 xv[kPart];
+#pragma unroll
+              for (int q = 0; q < kPart; ++q) xv[q] = xr[hq * kPart + q];
+#pragma unroll
+              for (int q = kPart - 1; q >= 0; --q) {
+                const int e4 = 4 * (hq * kPart + q);
+                acc += ereg[e4 + 3] * xv[q].w;
+                acc += ereg[e4 + 2] * xv[q].z;
+                acc += ereg[e4 + 1] * xv[q].y;
+                acc += ereg[e4 + 0] * xv[q].x;
+              }
             }
             if (lane < NC) {
               const uint64_t ix = (uint64_t)(NO + r) * CP + lane;

@@ -49,10 +49,12 @@ def main():
     el = time.perf_counter() - t0
     avg = sum(ms) / len(ms)
     # algorithmic HBM bytes per stream-byte: gate weights read once per forward (3 x 50 x 308 x 4),
-    # the output layer read and its next ring slot written (2 x 256 x 51 x 4), the records; per
-    # backward epoch (one per byte on average): 3 gates' accumulators read+written (2 x 3 x 50 x 308 x 4),
-    # the output layer of the epoch read again (256 x 51 x 4), Adam amortised (3 x 4 x 2 x 563 x 50 x 4 / 100)
-    bpb = 3 * 50 * 308 * 4 + 2 * 256 * 51 * 4 + 1024 + 2 * 3 * 50 * 308 * 4 + 256 * 51 * 4 + 3 * 4 * 2 * 563 * 50 * 4 // 100
+    # the output layer read twice (forward, SGD) and its next ring slot written (3 x 256 x 51 x 4),
+    # the records and the stored layer input (2 x 307 x 4 + 1024); per backward epoch (one per byte
+    # on average): the output layer of the epoch (256 x 51 x 4), the recurrent weights (3 x 50 x 50 x 4);
+    # per pass / 100: Adam's m, v, w read and written (3 x 6 x 563 x 50 x 4) and the layer inputs (4 x 307 x 100 x 4)
+    bpb = (3 * 50 * 308 * 4 + 3 * 256 * 51 * 4 + 2 * 307 * 4 + 1024 + 256 * 51 * 4 + 3 * 50 * 50 * 4
+           + (3 * 6 * 563 * 50 * 4 + 4 * 307 * 100 * 4) // 100)
     out = {"metric": "LSTM byte-model bytes/sec (Predict x 8 bits + Learn, backward pass every 100th byte)",
            "value": S * N * args.steps / el, "unit": "bytes/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
