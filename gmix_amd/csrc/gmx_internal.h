@@ -178,6 +178,9 @@ struct GmxLstmRunArgs {
   uint32_t* ctx_out;       // [S][*]
   uint64_t rec_stride, n_bytes;
   uint32_t learn, max_bptt;
+  uint32_t phases;         // 1: Lstm::Predict, 2: the 8 bit predictions, 4: Lstm::Perceive (when learn)
+  int32_t stream_base;     // bank of block 0 (records of block 0 are always stream 0 of the arrays)
+  int32_t last_byte;       // >= 0: ShortTermMemory::last_byte for the first Predict (else the bank remembers it)
 };
 
 #endif  // GMX_INTERNAL_H_

@@ -72,8 +72,8 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
   __shared__ Lds L;
   const GmxLstmDev& dv = *dvp;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int s = blockIdx.x;
-  float* const B = a.banks + (uint64_t)s * dv.bank_floats;
+  const int s = blockIdx.x;  // record stream; its bank:
+  float* const B = a.banks + (uint64_t)(a.stream_base + s) * dv.bank_floats;
   uint32_t* const scal = (uint32_t*)(B + dv.scal);
   uint32_t* const hist = (uint32_t*)(B + dv.input_history);
   float* const out_layer = B + dv.out_layer;
@@ -92,13 +92,14 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
   L.probs[tid] = (B + dv.probs)[tid];
   uint32_t epoch = scal[0], l_epoch = scal[1], update_steps = scal[2], last_byte = scal[3], context = scal[4];
   float prediction = __uint_as_float(scal[5]);
+  if (a.last_byte >= 0) last_byte = (uint32_t)a.last_byte;
   uint32_t bptt_done = 0;
   __syncthreads();
 
   for (uint64_t n = 0; n < a.n_bytes; ++n) {
     const uint32_t byte = bytes_s[n];
     // ======================= Lstm::Predict (lstm.cpp:95-123) ================================
-    {
+    if (a.phases & 1u) {
       const uint32_t e = epoch, le = l_epoch;
       float* const lin = B + dv.layer_input + (uint64_t)e * LINP;
       // SetInput + the recurrent part of the layer input (lstm.cpp:45-50, :98-100)
@@ -209,7 +210,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       context = pm > 0.0f ? L.ired[0] : 0u;
     }
     // ======================= the 8 bit predictions (lstm-model.cpp:34-48) ====================
-    if (tid < 8) {
+    if ((a.phases & 2u) && tid < 8) {
       const int k = tid;
       const int size = 256 >> k, half = size >> 1;
       const int bot = k == 0 ? 0 : (int)((byte >> (8 - k)) << (8 - k));
@@ -225,7 +226,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       L.nrm[1][k] = denom != 0.0f ? (p == 0.5f ? 1.0f : 2.0f) : 0.0f;  // 0 silent, 1 inactive, 2 active
     }
     __syncthreads();
-    if (tid == 0) {
+    if ((a.phases & 2u) && tid == 0) {
       for (int k = 0; k < 8; ++k) {  // in bit order: a silent bit leaves the previous prediction
         const float st = L.nrm[1][k];
         if (st != 0.0f) prediction = L.nrm[0][k];
@@ -234,8 +235,8 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       }
       ctx_s[n] = context;
     }
-    last_byte = byte;
-    if (!a.learn) {
+    if (a.phases & 6u) last_byte = byte;  // the byte is known from here on
+    if (!a.learn || !(a.phases & 4u)) {
       __syncthreads();
       continue;
     }

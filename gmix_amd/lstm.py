@@ -54,6 +54,19 @@ class LstmGroup:
         check(self.L.gmx_lstm_get_weights(self.h, stream, _vp(w), _vp(o)), "gmx_lstm_get_weights")
         return w, o
 
+    def forward(self, ppm, last_byte, stream=0):
+        """Lstm::Predict(last_byte) at a byte boundary: (probs[256], lstm_prediction_context)."""
+        x = np.ascontiguousarray(ppm, np.float32)
+        assert x.shape == (256,)
+        probs = np.zeros(256, np.float32)
+        ctx = C.c_uint32(0)
+        check(self.L.gmx_lstm_forward(self.h, stream, int(last_byte), _vp(x), _vp(probs), C.byref(ctx)),
+              "gmx_lstm_forward")
+        return probs, ctx.value
+
+    def perceive(self, byte, stream=0):
+        check(self.L.gmx_lstm_perceive(self.h, stream, int(byte)), "gmx_lstm_perceive")
+
     def run(self, batch, n_bytes=None, learn=True, timed=False):
         n = batch.max_bytes if n_bytes is None else n_bytes
         ms = C.c_float(0)

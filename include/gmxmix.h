@@ -277,6 +277,15 @@ int gmx_lstm_batch_wait(gmx_lstm_batch* b);
 /* LstmModel::Predict x 8 bits (+ LstmModel::Learn when learn != 0) for bytes [0, n_bytes) of every
  * stream. */
 int gmx_lstm_run(gmx_lstm* l, gmx_lstm_batch* b, uint64_t n_bytes, int learn, float* kernel_ms);
+/* Per-byte surface, for decoding (the byte is not known when its prediction is needed).
+ * forward = Lstm::SetInput + Lstm::Predict(last_byte) at a byte boundary (lstm-model.cpp:19-33,
+ * last_byte = ShortTermMemory::last_byte): probs[256]
+ * (nullable) = the byte distribution LstmModel keeps in probs_, *context (nullable) =
+ * lstm_prediction_context; the 8 bit predictions follow from probs and the decoded bits exactly as
+ * in LstmModel::Predict (lstm-model.cpp:34-48).  perceive = Lstm::Perceive(byte), i.e.
+ * LstmModel::Learn at the last bit of that byte. */
+int gmx_lstm_forward(gmx_lstm* l, int stream, int last_byte, const float* ppm, float* probs, uint32_t* context);
+int gmx_lstm_perceive(gmx_lstm* l, int stream, int byte);
 
 #ifdef __cplusplus
 }

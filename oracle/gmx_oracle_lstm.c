@@ -441,3 +441,11 @@ void gmxo_lstm_get_output_layer(const gmxo_lstm* l, float* out /* [H][NO][HID] *
   memcpy(out, l->out_layer, (size_t)H * NO * HID * 4);
 }
 uint64_t gmxo_lstm_update_steps(const gmxo_lstm* l) { return l->update_steps; }
+
+/* Byte-level entry points (what the per-byte device surface is compared with): Lstm::Predict at a
+ * byte boundary with the bookkeeping of LstmModel::Predict, and Lstm::Perceive. */
+void gmxo_lstm_predict_byte(gmxo_lstm* l, const float* ppm, uint32_t last_byte, float* probs_out, uint32_t* ctx_out) {
+  float prediction = 0;
+  gmxo_lstm_model_predict(l, 1, last_byte, 0, ppm, &prediction, ctx_out, probs_out);
+}
+void gmxo_lstm_perceive_byte(gmxo_lstm* l, uint32_t byte) { lstm_perceive(l, byte); }

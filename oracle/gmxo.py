@@ -348,6 +348,8 @@ def _lstm_lib():
         L.gmxo_lstm_run.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_void_p]
         L.gmxo_lstm_get_output_layer.argtypes = [C.c_void_p, C.c_void_p]
+        L.gmxo_lstm_predict_byte.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.gmxo_lstm_perceive_byte.argtypes = [C.c_void_p, C.c_uint32]
         L.gmxo_lstm_update_steps.restype = C.c_uint64
         L.gmxo_lstm_update_steps.argtypes = [C.c_void_p]
         L._lstm_ready = True
@@ -380,6 +382,16 @@ class LstmModel:
         o = np.zeros((100, 256, 51), np.float32)
         self.L.gmxo_lstm_get_output_layer(self.h, _p(o))
         return o
+
+    def predict_byte(self, ppm, last_byte):
+        x = np.ascontiguousarray(ppm, np.float32)
+        probs = np.zeros(256, np.float32)
+        ctx = C.c_uint32(0)
+        self.L.gmxo_lstm_predict_byte(self.h, _p(x), int(last_byte), _p(probs), C.byref(ctx))
+        return probs, ctx.value
+
+    def perceive_byte(self, byte):
+        self.L.gmxo_lstm_perceive_byte(self.h, int(byte))
 
     def run(self, ppm, data, learn=True):
         """Whole bytes through LstmModel::Predict x 8 (+ Learn): (pred[n,8], active[n,8], ctx[n])."""

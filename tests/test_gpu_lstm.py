@@ -115,3 +115,29 @@ def test_lstm_kernel_matches_reference_goldens(gpu, oracle, name):
         hw = ((hw ^ byte) * 0x100000001b3) & mask
     assert hw == meta["long_hash"]
     g.close()
+
+
+def test_lstm_per_byte_surface_for_decoding(gpu, oracle):
+    """gmx_lstm_forward / gmx_lstm_perceive: the byte distribution and lstm_prediction_context one
+    byte at a time, through a backward pass, then a batched launch continues the same stream."""
+    N = 230
+    ppm, data = oracle.lstm_synth(N, seed=21, mask=31)
+    m = oracle.LstmModel()
+    g = gpu.LstmGroup(2)
+    g.set_weights(m.weights(), stream=1)
+    last = 0
+    with pytest.raises(gpu.GmxError):
+        g.perceive(3, stream=1)                    # Perceive before any Predict
+    for n in range(130):
+        probs, ctx = g.forward(ppm[n], last, stream=1)
+        p_ref, c_ref = m.predict_byte(ppm[n], last)
+        assert np.array_equal(u32(probs), u32(p_ref)) and ctx == c_ref, n
+        if n % 50 == 7:                            # a byte whose bits are predicted but never learned
+            last = int(data[n])                    # (generation): the hidden state still moves on
+            continue
+        g.perceive(int(data[n]), stream=1)
+        m.perceive_byte(int(data[n]))
+        last = int(data[n])
+    w, o = g.get_weights(1)
+    assert np.array_equal(u32(w), u32(m.weights())) and np.array_equal(u32(o), u32(m.output_layer()))
+    g.close()
