@@ -140,6 +140,7 @@ def lib():
     L.gmx_lstm_run.argtypes = [vp, vp, u64, i32, C.POINTER(C.c_float)]
     L.gmx_lstm_forward.argtypes = [vp, i32, i32, vp, vp, C.POINTER(u32)]
     L.gmx_lstm_perceive.argtypes = [vp, i32, i32]
+    L.gmx_lstm_feed.argtypes = [vp, vp, u64, vp, i32, i32, vp, i32]
     L.gmx_debug_math_probe.argtypes = [i32, vp, vp, u64, i32]
     L.gmx_debug_math_range.argtypes = [i32, u64, u64, i32, C.POINTER(C.c_ulonglong)]
     _LIB = L
@@ -172,5 +173,5 @@ ABI_SYMBOLS = [
     "gmx_lstm_sync", "gmx_lstm_set_weights", "gmx_lstm_get_weights", "gmx_lstm_batch_create",
     "gmx_lstm_batch_destroy", "gmx_lstm_batch_ppm", "gmx_lstm_batch_bytes", "gmx_lstm_batch_predictions",
     "gmx_lstm_batch_active", "gmx_lstm_batch_contexts", "gmx_lstm_batch_upload", "gmx_lstm_batch_download",
-    "gmx_lstm_batch_wait", "gmx_lstm_run", "gmx_lstm_forward", "gmx_lstm_perceive",
+    "gmx_lstm_batch_wait", "gmx_lstm_run", "gmx_lstm_forward", "gmx_lstm_perceive", "gmx_lstm_feed",
 ]

@@ -465,3 +465,46 @@ extern "C" hipError_t gmx_launch_lstm_kernel(const GmxLstmDev* dv, const GmxLstm
   hipLaunchKernelGGL(gmx_lstm_kernel, dim3(n_streams), dim3(256), 0, stream, dv, *args);
   return hipGetLastError();
 }
+
+// Scatter of a batch's results into the record arrays of the models downstream (device to
+// device): the prediction of bit k of byte n goes to slot `slot` of record 8n+k of a mixer batch
+// (and its active flag into that record's mask), lstm_prediction_context of byte n into column
+// mixer_ctx_col of the 8 mixer records and column ind_ctx_col of the 8 Indirect records.
+struct GmxLstmScatterArgs {
+  const float* pred;       // [S][rec_stride][8]
+  const uint8_t* act;
+  const uint32_t* ctx;     // [S][rec_stride]
+  uint64_t rec_stride, n_bytes;
+  float* mx_pred;          // [S][mx_stride][mx_n_pad] or null
+  uint32_t* mx_mask;       // [S][mx_stride][mx_mask_words]
+  uint32_t* mx_ctx;        // [S][mx_stride][mx_m]
+  uint64_t mx_stride;
+  int32_t mx_n_pad, mx_mask_words, mx_m, slot, mixer_ctx_col;
+  uint32_t* ind_ctx;       // [S][ind_stride][ind_k] or null
+  uint64_t ind_stride;
+  int32_t ind_k, ind_ctx_col;
+};
+
+__global__ void __launch_bounds__(256) gmx_lstm_scatter_kernel(const GmxLstmScatterArgs a) {
+  const int s = blockIdx.y;
+  const uint64_t bit = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  if (bit >= a.n_bytes * 8) return;
+  const uint64_t n = bit >> 3;
+  const uint32_t c = a.ctx[(uint64_t)s * a.rec_stride + n];
+  if (a.mx_pred) {
+    const uint64_t r = (uint64_t)s * a.mx_stride + bit;
+    a.mx_pred[r * a.mx_n_pad + a.slot] = a.pred[((uint64_t)s * a.rec_stride + n) * 8 + (bit & 7)];
+    uint32_t* w = a.mx_mask + r * a.mx_mask_words + (a.slot >> 5);
+    const uint32_t m = 1u << (a.slot & 31);
+    *w = a.act[((uint64_t)s * a.rec_stride + n) * 8 + (bit & 7)] ? (*w | m) : (*w & ~m);
+    if (a.mixer_ctx_col >= 0) a.mx_ctx[r * a.mx_m + a.mixer_ctx_col] = c;
+  }
+  if (a.ind_ctx) a.ind_ctx[((uint64_t)s * a.ind_stride + bit) * a.ind_k + a.ind_ctx_col] = c;
+}
+
+extern "C" hipError_t gmx_launch_lstm_scatter(const GmxLstmScatterArgs* args, int n_streams, hipStream_t stream) {
+  (void)hipGetLastError();
+  const unsigned blocks = (unsigned)((args->n_bytes * 8 + 255) / 256);
+  hipLaunchKernelGGL(gmx_lstm_scatter_kernel, dim3(blocks, n_streams), dim3(256), 0, stream, *args);
+  return hipGetLastError();
+}

@@ -67,6 +67,10 @@ class LstmGroup:
     def perceive(self, byte, stream=0):
         check(self.L.gmx_lstm_perceive(self.h, stream, int(byte)), "gmx_lstm_perceive")
 
+    def feed(self, batch, n_bytes, mixer_batch=None, slot=1, mixer_ctx_col=-1, ind_batch=None, ind_ctx_col=0):
+        check(self.L.gmx_lstm_feed(self.h, batch.h, n_bytes, mixer_batch.h if mixer_batch else None, slot,
+                                   mixer_ctx_col, ind_batch.h if ind_batch else None, ind_ctx_col), "gmx_lstm_feed")
+
     def run(self, batch, n_bytes=None, learn=True, timed=False):
         n = batch.max_bytes if n_bytes is None else n_bytes
         ms = C.c_float(0)

@@ -284,6 +284,14 @@ int gmx_lstm_run(gmx_lstm* l, gmx_lstm_batch* b, uint64_t n_bytes, int learn, fl
  * lstm_prediction_context; the 8 bit predictions follow from probs and the decoded bits exactly as
  * in LstmModel::Predict (lstm-model.cpp:34-48).  perceive = Lstm::Perceive(byte), i.e.
  * LstmModel::Learn at the last bit of that byte. */
+/* Hand a batch's results to the models downstream, device to device, after gmx_lstm_run:
+ * mixer_batch (nullable; created with GMX_BATCH_MASK, max_bits >= 8 * n_bytes): the prediction of
+ * bit k of byte n goes to slot `slot` (the LSTM's prediction index) of record 8n+k, its active
+ * flag into that record's mask, lstm_prediction_context into gate-context column mixer_ctx_col
+ * (< 0: none) of the 8 records; ind_batch (nullable): the context into column ind_ctx_col of the
+ * 8 Indirect records (the model built on lstm_prediction_context, predictor.cpp:117-119). */
+int gmx_lstm_feed(gmx_lstm* l, gmx_lstm_batch* b, uint64_t n_bytes, gmx_batch* mixer_batch, int slot,
+                  int mixer_ctx_col, gmx_ind_batch* ind_batch, int ind_ctx_col);
 int gmx_lstm_forward(gmx_lstm* l, int stream, int last_byte, const float* ppm, float* probs, uint32_t* context);
 int gmx_lstm_perceive(gmx_lstm* l, int stream, int byte);
 
