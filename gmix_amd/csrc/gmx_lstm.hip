@@ -98,6 +98,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
 
   for (uint64_t n = 0; n < a.n_bytes; ++n) {
     const uint32_t byte = bytes_s[n];
+    bool sgd_done = false;
     // ======================= Lstm::Predict (lstm.cpp:95-123) ================================
     if (a.phases & 1u) {
       const uint32_t e = epoch, le = l_epoch;
@@ -163,13 +164,11 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       // output layer + softmax (lstm.cpp:106-118): thread = output symbol
       const float* ol = out_layer + (uint64_t)e * HID * NO;
       float sum = 0.0f;
-      {
-        float ov[HID];
+      float ov[HID];
 #pragma unroll
-        for (int j = 0; j < HID; ++j) ov[j] = ol[(uint64_t)j * NO + tid];
+      for (int j = 0; j < HID; ++j) ov[j] = ol[(uint64_t)j * NO + tid];
 #pragma unroll
-        for (int j = 0; j < HID; ++j) sum += L.hid[j] * ov[j];
-      }
+      for (int j = 0; j < HID; ++j) sum += L.hid[j] * ov[j];
       // max_out = max(0, every sum): order does not matter for a maximum
       float mx = sum > 0.0f ? sum : 0.0f;
       for (int o = 32; o > 0; o >>= 1) {
@@ -194,6 +193,19 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       (B + dv.output + (uint64_t)e * NO)[tid] = p;
       epoch = epoch + 1 == H ? 0 : epoch + 1;
       l_epoch = l_epoch + 1 == H ? 0 : l_epoch + 1;
+      // The output layer's own step (lstm.cpp:86-92) belongs to Lstm::Perceive of this byte, but
+      // when no backward pass comes first (epoch != 0) nothing it reads changes until then: it
+      // starts from the matrix column this thread still holds, so do it now and read the ring
+      // slot once instead of twice.  (Only when this launch also perceives, and knows the byte.)
+      sgd_done = false;
+      if (a.learn && (a.phases & 4u) && epoch != 0) {
+        const float error = ((uint32_t)tid == byte) ? (p - 1.0f) : p;
+        const float lr_e = kLearningRate * error;
+        float* dst = out_layer + (uint64_t)epoch * HID * NO;
+#pragma unroll
+        for (int j = 0; j < HID; ++j) dst[(uint64_t)j * NO + tid] = ov[j] - lr_e * L.hid[j];
+        sgd_done = true;
+      }
       // lstm_prediction_context: the first symbol with the largest probability (lstm-model.cpp:25-33)
       float pm = p;
       for (int o = 32; o > 0; o >>= 1) {
@@ -428,8 +440,8 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       __syncthreads();
       ++bptt_done;
     }
-    // the output layer's own step (lstm.cpp:86-92): thread = output symbol
-    {
+    // the output layer's own step (lstm.cpp:86-92) when the forward pass could not take it along
+    if (!sgd_done) {
       const float o = (B + dv.output + (uint64_t)last_epoch * NO)[tid];
       const float error = ((uint32_t)tid == byte) ? (o - 1.0f) : o;
       const float le = kLearningRate * error;
