@@ -143,3 +143,17 @@ def test_indirect_descriptions_are_validated_before_any_device_is_touched():
     assert create([(256, 0.02, 2 * i, 2 * i + 1) for i in range(65)]) == -1   # more than 64 models
     if gmix_amd.device_count() == 0:
         assert create([(256, 0.02, 0, 1)]) == -4              # valid, but nothing to run it on
+
+
+def test_lstm_entry_points_reject_bad_arguments():
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.gmx_lstm_create(C.byref(h), 0, 0) == -1          # no streams
+    assert L.gmx_lstm_create(None, 1, 0) == -1
+    if gmix_amd.device_count() == 0:
+        assert L.gmx_lstm_create(C.byref(h), 1, 0) == -4      # no CPU fallback
+    assert L.gmx_lstm_run(None, None, 1, 1, None) == -1
+    assert L.gmx_lstm_forward(None, 0, 0, None, None, None) == -1
+    assert L.gmx_lstm_perceive(None, 0, 3) == -1
+    assert L.gmx_lstm_feed(None, None, 1, None, 1, -1, None, 0) == -1
+    assert L.gmx_lstm_bank_bytes(None) == 0
