@@ -449,3 +449,6 @@ void gmxo_lstm_predict_byte(gmxo_lstm* l, const float* ppm, uint32_t last_byte, 
   gmxo_lstm_model_predict(l, 1, last_byte, 0, ppm, &prediction, ctx_out, probs_out);
 }
 void gmxo_lstm_perceive_byte(gmxo_lstm* l, uint32_t byte) { lstm_perceive(l, byte); }
+
+/* FNV-1a 64 of a byte array (the harnesses' checksum), for the tests. */
+uint64_t gmxo_fnv64_bytes(const uint8_t* p, uint64_t n) { return fnv(0xcbf29ce484222325ull, p, n); }

@@ -450,3 +450,11 @@ def lstm_synth(n_bytes, seed=0, mask=255):
     data = np.zeros(n_bytes, np.uint8)
     L.gmxo_lstm_synth_fill(seed, mask, n_bytes, _p(ppm), _p(data))
     return ppm, data
+
+
+def fnv64_bytes(a):
+    L = _lstm_lib()
+    L.gmxo_fnv64_bytes.restype = C.c_uint64
+    L.gmxo_fnv64_bytes.argtypes = [C.c_void_p, C.c_uint64]
+    b = np.ascontiguousarray(a, np.uint8).reshape(-1)
+    return int(L.gmxo_fnv64_bytes(_p(b), len(b)))
