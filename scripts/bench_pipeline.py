@@ -21,8 +21,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=256)
     ap.add_argument("--bytes", type=int, default=200)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
     args = ap.parse_args()
     import gmix_amd
     import goldenlib
@@ -36,7 +36,10 @@ def main():
     lg = gmix_amd.LstmGroup(S)
     ig = gmix_amd.IndirectGroup(models, z["ns_next"], z["rm_next"], S, slots=slots)
     mg = gmix_amd.MixerGroup(topology.stock(90), S)
-    lb, ib, mb = gmix_amd.LstmBatch(lg, NB), gmix_amd.IndirectBatch(ig, T), gmix_amd.Batch(mg, T, outputs=False, mask=True)
+    # two sets of downstream records: the LSTM works on step k+1 while the mixers still read step k's
+    lb = gmix_amd.LstmBatch(lg, NB)
+    ibs = [gmix_amd.IndirectBatch(ig, T) for _ in range(2)]
+    mbs = [gmix_amd.Batch(mg, T, outputs=False, mask=True) for _ in range(2)]
     w = gmxo.LstmModel().weights()
     ppm, data = gmxo.lstm_synth(NB, seed=1, mask=63)
     rng = np.random.default_rng(0)
@@ -44,23 +47,25 @@ def main():
         lg.set_weights(w, stream=s)
         lb.ppm[s] = ppm
         lb.bytes[s] = np.roll(data, int(rng.integers(0, NB)))
-    ib.fill_synthetic(T, seed=3, restart=True, ctx_mod=(300, 0, 70000, 5))     # contexts, bit contexts (bits come from ...)
-    mb.fill_synthetic(T, seed=5, restart=True, ctx_mode=2, zero_mod=12)        # the 7 other inputs, mixer contexts
+    for i in range(2):
+        ibs[i].fill_synthetic(T, seed=3 + i, restart=True, ctx_mod=(300, 0, 70000, 5))   # contexts, bit contexts, bits
+        mbs[i].fill_synthetic(T, seed=5 + i, restart=True, ctx_mode=2, zero_mod=12)      # the 7 other inputs, mixer contexts
     lb.upload(NB)
     lg.sync(); ig.sync(); mg.sync()
 
-    def step():
+    def step(k):
+        ib, mb = ibs[k & 1], mbs[k & 1]
         lg.run(lb, NB, learn=True)
         lg.feed(lb, NB, mixer_batch=mb, slot=1, mixer_ctx_col=22, ind_batch=ib, ind_ctx_col=16)
         ig.run(ib, T, learn=True, into=mb)
         mg.run(mb, T, learn=True)
 
-    for _ in range(args.warmup):
-        step()
-    mg.sync()
+    for k in range(args.warmup):
+        step(k)
+    lg.sync(); ig.sync(); mg.sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
     lg.sync(); ig.sync(); mg.sync()
     el = time.perf_counter() - t0
     print(json.dumps({
