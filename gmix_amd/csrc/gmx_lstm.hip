@@ -39,7 +39,6 @@
 #define GMX_LSTM_Q 16
 #define GMX_LSTM_BLOCKS 3
 #define GMX_LSTM_ADAM 12
-#define GMX_LSTM_XPARTS 5   /* 1 or 5: parts the 100 epochs of a row are fetched in */
 #endif
 
 namespace {
@@ -49,11 +48,14 @@ constexpr int NI = GMX_L_NI, NO = GMX_L_NO, NC = GMX_L_NC, H = GMX_L_H, LIN = GM
 constexpr float kLearningRate = 0.03f, kClip = 10.0f;
 constexpr uint32_t kUpdateLimit = 3000;
 
+constexpr int kTileRows = 16;  // layer-input rows of the deferred accumulation staged at a time
+
 struct Lds {
+  alignas(16) float probs[NO];   // LstmModel::probs_ / softmax scratch
+  alignas(16) float xt[kTileRows][GMX_L_HP];  // input-major layer inputs of a tile of rows
   float xin[LINP];        // layer input of the epoch at hand
   float hid[CP];          // Lstm::hidden_ (hid[50] = 1)
   float herr[CP];         // Lstm::hidden_error_
-  float probs[NO];        // LstmModel::probs_ / softmax scratch
   float err[NO];          // output-layer error of an epoch
   float nrm[3][CP];       // per gate: pre-norm sums / products for the ordered reductions
   float act[3][CP];       // per gate: activated state of the forward pass / final errors backward
@@ -62,6 +64,24 @@ struct Lds {
   uint32_t ired[4];
   uint64_t exptab[32];
 };
+
+// acc + p[0] + p[1] + ... + p[n-1], strictly in that order, n a multiple of 4 up to 4*Q4, p 16-byte
+// aligned in LDS: the reads are issued as independent 16-byte loads, the adds follow in order.
+template <int Q4>
+__device__ __forceinline__ float ordered_sum4(float acc, const float* p, int n) {
+  float4 v[Q4];
+#pragma unroll
+  for (int q = 0; q < Q4; ++q) v[q] = *(const float4*)(p + 4 * (4 * q < n ? q : 0));
+#pragma unroll
+  for (int q = 0; q < Q4; ++q)
+    if (4 * q < n) {
+      acc += v[q].x;
+      acc += v[q].y;
+      acc += v[q].z;
+      acc += v[q].w;
+    }
+  return acc;
+}
 
 __device__ __forceinline__ float clipf(float a) { return a < -kClip ? -kClip : (a > kClip ? kClip : a); }
 
@@ -181,9 +201,10 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       for (int k = 1; k < 4; ++k) mx = L.red[4 + k] > mx ? L.red[4 + k] : mx;
       L.probs[tid] = gmx_expf_tab(sum - mx, L.exptab);
       __syncthreads();
-      if (tid == 0) {  // valarray::sum(): first element first
-        float t = L.probs[0];
-        for (int i = 1; i < NO; ++i) t += L.probs[i];
+      if (tid == 0) {  // valarray::sum(): first element first (0 + p[0] is p[0])
+        float t = 0.0f;
+#pragma unroll 1
+        for (int o = 0; o < NO; o += 64) t = ordered_sum4<16>(t, L.probs + o, 64);
         L.red[0] = t;
       }
       __syncthreads();
@@ -227,10 +248,19 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       const int size = 256 >> k, half = size >> 1;
       const int bot = k == 0 ? 0 : (int)((byte >> (8 - k)) << (8 - k));
       const int mid = bot + half - 1, top = bot + size - 1;
-      float num = 0.0f;
-      for (int i = mid + 1; i <= top; ++i) num += L.probs[i];
-      float denom = num;
-      for (int i = bot; i <= mid; ++i) denom += L.probs[i];
+      // std::accumulate from 0.0f over the upper half, then on over the lower half
+      float num = 0.0f, denom;
+      if (half >= 4) {
+#pragma unroll 1
+        for (int o = 0; o < half; o += 64) num = ordered_sum4<16>(num, L.probs + mid + 1 + o, half - o < 64 ? half - o : 64);
+        denom = num;
+#pragma unroll 1
+        for (int o = 0; o < half; o += 64) denom = ordered_sum4<16>(denom, L.probs + bot + o, half - o < 64 ? half - o : 64);
+      } else {
+        for (int i = mid + 1; i <= top; ++i) num += L.probs[i];
+        denom = num;
+        for (int i = bot; i <= mid; ++i) denom += L.probs[i];
+      }
       // SetPrediction (short-term-memory.cpp:187-191); a silent bit (denom == 0) keeps the slot
       const float p = num / denom;
       L.nrm[0][k] = gmx_logit(p);
@@ -400,27 +430,32 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
 #pragma unroll
           for (int ep = 0; ep < H; ++ep) ereg[ep] = (B + dv.errs + ((uint64_t)g * H + ep) * CP)[cl];
 #pragma unroll 1
-          for (int r = wave; r < LIN; r += 4) {
-            const float4* xr = (const float4*)(B + dv.lin_t + (uint64_t)r * GMX_L_HP);
-            float acc = 0.0f;
-#pragma unroll
-            for (int hq = GMX_LSTM_XPARTS - 1; hq >= 0; --hq) {  // epochs 99 down to 0, a part at a time
-              constexpr int kPart = H / 4 / GMX_LSTM_XPARTS;
-              float4 xv[kPart];
-#pragma unroll
-              for (int q = 0; q < kPart; ++q) xv[q] = xr[hq * kPart + q];
-#pragma unroll
-              for (int q = kPart - 1; q >= 0; --q) {
-                const int e4 = 4 * (hq * kPart + q);
-                acc += ereg[e4 + 3] * xv[q].w;
-                acc += ereg[e4 + 2] * xv[q].z;
-                acc += ereg[e4 + 1] * xv[q].y;
-                acc += ereg[e4 + 0] * xv[q].x;
-              }
+          for (int r0 = 0; r0 < LIN; r0 += kTileRows) {
+            // stage the tile's rows (one row = one input over the 100 epochs) in LDS, coalesced
+            __syncthreads();
+            for (int i = tid; i < kTileRows * GMX_L_HP; i += 256) {
+              const int rr = r0 + i / GMX_L_HP;
+              (&L.xt[0][0])[i] = rr < LIN ? (B + dv.lin_t)[(uint64_t)r0 * GMX_L_HP + i] : 0.0f;
             }
-            if (lane < NC) {
-              const uint64_t ix = (uint64_t)(NO + r) * CP + lane;
-              adam1(acc, B + go.m + ix, B + go.v + ix, B + go.weights + ix);
+            __syncthreads();
+#pragma unroll 1
+            for (int t = wave; t < kTileRows; t += 4) {
+              const int r = r0 + t;
+              if (r >= LIN) break;
+              const float4* xr = (const float4*)L.xt[t];
+              float acc = 0.0f;
+#pragma unroll
+              for (int q = H / 4 - 1; q >= 0; --q) {  // epochs 99 down to 0
+                const float4 x = xr[q];
+                acc += ereg[4 * q + 3] * x.w;
+                acc += ereg[4 * q + 2] * x.z;
+                acc += ereg[4 * q + 1] * x.y;
+                acc += ereg[4 * q + 0] * x.x;
+              }
+              if (lane < NC) {
+                const uint64_t ix = (uint64_t)(NO + r) * CP + lane;
+                adam1(acc, B + go.m + ix, B + go.v + ix, B + go.weights + ix);
+              }
             }
           }
           if (lane < NC) {
