@@ -41,6 +41,22 @@
 #define GMX_LSTM_ADAM 12
 #endif
 
+// Phase profile (build with -DGMX_LSTM_PROF, read with gmx_lstm_prof_read): s_memtime ticks that
+// thread 0 of block 0 spends between consecutive stamps, summed per stamp id.
+#ifdef GMX_LSTM_PROF
+__device__ unsigned long long gmx_lstm_prof[16];
+#define STAMP(i)                                                 \
+  do {                                                           \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                   \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+      gmx_lstm_prof[i] += now_ - tprev_;                         \
+      tprev_ = now_;                                             \
+    }                                                            \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+
 namespace {
 
 constexpr int NI = GMX_L_NI, NO = GMX_L_NO, NC = GMX_L_NC, H = GMX_L_H, LIN = GMX_L_LIN, LINP = GMX_L_LINP,
@@ -56,7 +72,7 @@ struct Lds {
   float xin[LINP];        // layer input of the epoch at hand
   float hid[CP];          // Lstm::hidden_ (hid[50] = 1)
   float herr[CP];         // Lstm::hidden_error_
-  float err[NO];          // output-layer error of an epoch
+  alignas(16) float err[NO];  // output-layer error of an epoch
   float nrm[3][CP];       // per gate: pre-norm sums / products for the ordered reductions
   float act[3][CP];       // per gate: activated state of the forward pass / final errors backward
   float fsum[3][CP];
@@ -116,8 +132,12 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
   uint32_t bptt_done = 0;
   __syncthreads();
 
+#ifdef GMX_LSTM_PROF
+  unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
   for (uint64_t n = 0; n < a.n_bytes; ++n) {
     const uint32_t byte = bytes_s[n];
+    STAMP(0);
     bool sgd_done = false;
     // ======================= Lstm::Predict (lstm.cpp:95-123) ================================
     if (a.phases & 1u) {
@@ -133,6 +153,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
         lin[j] = L.xin[j];
         (B + dv.lin_t)[(uint64_t)j * GMX_L_HP + e] = L.xin[j];
       }
+      STAMP(1);  // inputs
       // LstmLayer::ForwardPass(NeuronLayer&) (lstm-layer.cpp:221-241): wave = gate, lane = cell
       if (wave < 3 && lane < NC) {
         const GmxLstmGateOff& g = dv.gate[wave];
@@ -151,9 +172,17 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
         L.nrm[wave][lane] = f;
       }
       __syncthreads();
+      STAMP(2);  // gate chains
       if (wave < 3 && lane == 0) {
         float sq = L.nrm[wave][NC - 1] * L.nrm[wave][NC - 1];  // expression .sum(): last element first
-        for (int i = NC - 2; i >= 0; --i) sq += L.nrm[wave][i] * L.nrm[wave][i];
+#pragma unroll 1
+        for (int i0 = NC - 1 - 7; i0 >= 0; i0 -= 7) {  // the other 49, seven LDS reads at a time
+          float nv[7];
+#pragma unroll
+          for (int u = 0; u < 7; ++u) nv[u] = L.nrm[wave][i0 + u];
+#pragma unroll
+          for (int u = 6; u >= 0; --u) sq += nv[u] * nv[u];
+        }
         const float iv = 1.0f / sqrtf((sq / (float)NC) + 1e-5f);
         L.red[wave] = iv;
         (B + dv.gate[wave].ivar)[le] = iv;
@@ -181,6 +210,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
         L.hid[tid] = L.act[2][tid] * ts;
       }
       __syncthreads();
+      STAMP(3);  // norm, activations, cell
       // output layer + softmax (lstm.cpp:106-118): thread = output symbol
       const float* ol = out_layer + (uint64_t)e * HID * NO;
       float sum = 0.0f;
@@ -201,6 +231,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       for (int k = 1; k < 4; ++k) mx = L.red[4 + k] > mx ? L.red[4 + k] : mx;
       L.probs[tid] = gmx_expf_tab(sum - mx, L.exptab);
       __syncthreads();
+      STAMP(4);  // output layer, max, expf
       if (tid == 0) {  // valarray::sum(): first element first (0 + p[0] is p[0])
         float t = 0.0f;
 #pragma unroll 1
@@ -242,6 +273,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       __syncthreads();
       context = pm > 0.0f ? L.ired[0] : 0u;
     }
+    STAMP(5);  // softmax sum, divide, context, early SGD
     // ======================= the 8 bit predictions (lstm-model.cpp:34-48) ====================
     if ((a.phases & 2u) && tid < 8) {
       const int k = tid;
@@ -282,6 +314,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       __syncthreads();
       continue;
     }
+    STAMP(6);  // bits
     // ======================= Lstm::Perceive (lstm.cpp:52-93) ================================
     const uint32_t last_epoch = epoch == 0 ? H - 1 : epoch - 1;
     const uint32_t old_input = hist[last_epoch];
@@ -291,6 +324,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
     if (epoch == 0) {
       const float alpha = adam_s[bptt_done * 4 + 0], d1 = adam_s[bptt_done * 4 + 1], d2 = adam_s[bptt_done * 4 + 2];
       for (int ep = H - 1; ep >= 0; --ep) {
+        STAMP(10);  // (previous epoch: neuron backward, clips)
         // output-layer error of this epoch and its pull on the hidden state (lstm.cpp:61-69)
         {
           const float o = (B + dv.output + (uint64_t)ep * NO)[tid];
@@ -308,10 +342,11 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
             for (int u = 0; u < GMX_LSTM_Q; ++u) ov[u] = *(const float4*)(ol + i0 + 4 * u);
 #pragma unroll
             for (int u = 0; u < GMX_LSTM_Q; ++u) {
-              he += ov[u].x * L.err[i0 + 4 * u + 0];
-              he += ov[u].y * L.err[i0 + 4 * u + 1];
-              he += ov[u].z * L.err[i0 + 4 * u + 2];
-              he += ov[u].w * L.err[i0 + 4 * u + 3];
+              const float4 ev = *(const float4*)(L.err + i0 + 4 * u);
+              he += ov[u].x * ev.x;
+              he += ov[u].y * ev.y;
+              he += ov[u].z * ev.z;
+              he += ov[u].w * ev.w;
             }
           }
           L.herr[tid] = he;
@@ -319,6 +354,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
         __syncthreads();
         const uint32_t prev_epoch = ep == 0 ? H - 1 : ep - 1;
         const uint32_t symbol = ep == 0 ? old_input : hist[prev_epoch];
+        STAMP(7);  // error + hidden-error chain
         // LstmLayer::BackwardPass (lstm-layer.cpp:252-292)
         if (tid < NC) {
           const int i = tid;
@@ -349,6 +385,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
         }
         if (ep == 0 && update_steps < kUpdateLimit) ++update_steps;
         __syncthreads();
+        STAMP(8);  // layer backward
         // LstmLayer::BackwardPass(NeuronLayer&) (lstm-layer.cpp:294-355): wave = gate, lane = cell
         float err = 0.0f, nv = 0.0f;
         if (wave < 3 && lane < NC) {
@@ -369,7 +406,14 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
         __syncthreads();
         if (wave < 3 && lane == 0) {
           float t = L.nrm[wave][NC - 1];  // expression .sum(): last element first
-          for (int i = NC - 2; i >= 0; --i) t += L.nrm[wave][i];
+#pragma unroll 1
+          for (int i0 = NC - 1 - 7; i0 >= 0; i0 -= 7) {
+            float nv[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) nv[u] = L.nrm[wave][i0 + u];
+#pragma unroll
+            for (int u = 6; u >= 0; --u) t += nv[u];
+          }
           L.red[wave] = t / (float)NC;
         }
         __syncthreads();
@@ -408,6 +452,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
         __syncthreads();
       }
       __syncthreads();
+      STAMP(10);
       // update_[cell][256 + r] (lstm-layer.cpp:341) formed in a register -- the epochs' products
       // added in the reference's order, 99 down to 0 -- and handed to Adam (lstm-layer.cpp:12-35)
       // right away; then the symbol columns and the layer-norm parameters.
@@ -438,11 +483,23 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
               (&L.xt[0][0])[i] = rr < LIN ? (B + dv.lin_t)[(uint64_t)r0 * GMX_L_HP + i] : 0.0f;
             }
             __syncthreads();
-#pragma unroll 1
-            for (int t = wave; t < kTileRows; t += 4) {
-              const int r = r0 + t;
-              if (r >= LIN) break;
-              const float4* xr = (const float4*)L.xt[t];
+            // this wave's rows of the tile: wave, wave + 4, ...; the Adam operands of the next row
+            // are requested before the 100-term sum of the current one runs
+            constexpr int kMine = kTileRows / 4;
+            auto row_ix = [&](int u) {
+              const int r = r0 + wave + 4 * u;
+              return (uint64_t)(NO + (r < LIN ? r : LIN - 1)) * CP + cl;
+            };
+            float am = (B + go.m)[row_ix(0)], av = (B + go.v)[row_ix(0)], aw = (B + go.weights)[row_ix(0)];
+#pragma unroll
+            for (int u = 0; u < kMine; ++u) {
+              float nm = 0.0f, nvv = 0.0f, nw = 0.0f;
+              if (u + 1 < kMine) {
+                nm = (B + go.m)[row_ix(u + 1)];
+                nvv = (B + go.v)[row_ix(u + 1)];
+                nw = (B + go.weights)[row_ix(u + 1)];
+              }
+              const float4* xr = (const float4*)L.xt[wave + 4 * u];
               float acc = 0.0f;
 #pragma unroll
               for (int q = H / 4 - 1; q >= 0; --q) {  // epochs 99 down to 0
@@ -452,10 +509,20 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
                 acc += ereg[4 * q + 1] * x.y;
                 acc += ereg[4 * q + 0] * x.x;
               }
-              if (lane < NC) {
+              const int r = r0 + wave + 4 * u;
+              if (r < LIN && lane < NC) {
                 const uint64_t ix = (uint64_t)(NO + r) * CP + lane;
-                adam1(acc, B + go.m + ix, B + go.v + ix, B + go.weights + ix);
+                float m = am * beta1;
+                m += (1.0f - beta1) * acc;
+                float v = av * beta2;
+                v += (1.0f - beta2) * acc * acc;
+                (B + go.m)[ix] = m;
+                (B + go.v)[ix] = v;
+                (B + go.weights)[ix] = aw - alpha * ((m / d1) / (sqrtf(v / d2 + eps)));
               }
+              am = nm;
+              av = nvv;
+              aw = nw;
             }
           }
           if (lane < NC) {
@@ -475,6 +542,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       __syncthreads();
       ++bptt_done;
     }
+    STAMP(9);  // deferred accumulation + Adam (backward bytes)
     // the output layer's own step (lstm.cpp:86-92) when the forward pass could not take it along
     if (!sgd_done) {
       const float o = (B + dv.output + (uint64_t)last_epoch * NO)[tid];
@@ -505,6 +573,12 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
     scal[5] = __float_as_uint(prediction);
   }
 }
+
+#ifdef GMX_LSTM_PROF
+extern "C" int gmx_lstm_prof_read(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gmx_lstm_prof), sizeof(unsigned long long) * 16);
+}
+#endif
 
 extern "C" hipError_t gmx_launch_lstm_kernel(const GmxLstmDev* dv, const GmxLstmRunArgs* args, int n_streams,
                                              hipStream_t stream) {
