@@ -64,7 +64,7 @@ constexpr int NI = GMX_L_NI, NO = GMX_L_NO, NC = GMX_L_NC, H = GMX_L_H, LIN = GM
 constexpr float kLearningRate = 0.03f, kClip = 10.0f;
 constexpr uint32_t kUpdateLimit = 3000;
 
-constexpr int kTileRows = 16;  // layer-input rows of the deferred accumulation staged at a time
+constexpr int kTileRows = 32;  // layer-input rows of the deferred accumulation staged at a time
 
 struct Lds {
   alignas(16) float probs[NO];   // LstmModel::probs_ / softmax scratch
@@ -474,6 +474,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
           float ereg[H];
 #pragma unroll
           for (int ep = 0; ep < H; ++ep) ereg[ep] = (B + dv.errs + ((uint64_t)g * H + ep) * CP)[cl];
+          STAMP(11);  // (the gate's error vectors into registers)
 #pragma unroll 1
           for (int r0 = 0; r0 < LIN; r0 += kTileRows) {
             // stage the tile's rows (one row = one input over the 100 epochs) in LDS, coalesced
@@ -483,6 +484,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
               (&L.xt[0][0])[i] = rr < LIN ? (B + dv.lin_t)[(uint64_t)r0 * GMX_L_HP + i] : 0.0f;
             }
             __syncthreads();
+            STAMP(12);  // (tile staged)
             // this wave's rows of the tile: wave, wave + 4, ...; the Adam operands of the next row
             // are requested before the 100-term sum of the current one runs
             constexpr int kMine = kTileRows / 4;
@@ -524,14 +526,34 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
               av = nvv;
               aw = nw;
             }
+            STAMP(13);  // (sums + Adam of the tile's rows)
           }
-          if (lane < NC) {
-#pragma unroll 4
-            for (int r = wave; r < NO; r += 4) {
-              const uint64_t ix = (uint64_t)r * CP + lane;
-              adam1((B + go.update)[ix], B + go.m + ix, B + go.v + ix, B + go.weights + ix);
+          if (lane < NC) {  // the symbol columns: 16 rows' operands requested at a time
+#pragma unroll 1
+            for (int r0 = wave; r0 < NO; r0 += 4 * 16) {
+              float ug[16], um[16], uv[16], uw[16];
+#pragma unroll
+              for (int u = 0; u < 16; ++u) {
+                const uint64_t ix = (uint64_t)(r0 + 4 * u) * CP + lane;
+                ug[u] = (B + go.update)[ix];
+                um[u] = (B + go.m)[ix];
+                uv[u] = (B + go.v)[ix];
+                uw[u] = (B + go.weights)[ix];
+              }
+#pragma unroll
+              for (int u = 0; u < 16; ++u) {
+                const uint64_t ix = (uint64_t)(r0 + 4 * u) * CP + lane;
+                float m = um[u] * beta1;
+                m += (1.0f - beta1) * ug[u];
+                float v = uv[u] * beta2;
+                v += (1.0f - beta2) * ug[u] * ug[u];
+                (B + go.m)[ix] = m;
+                (B + go.v)[ix] = v;
+                (B + go.weights)[ix] = uw[u] - alpha * ((m / d1) / (sqrtf(v / d2 + eps)));
+              }
             }
           }
+          STAMP(14);  // (Adam of the symbol columns)
         }
         if (wave < 3 && lane < NC) {
           const GmxLstmGateOff& go = dv.gate[wave];

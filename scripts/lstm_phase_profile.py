@@ -27,7 +27,9 @@ out = (C.c_ulonglong * 16)()
 g.L.gmx_lstm_prof_read(out)
 names = ["loop top", "inputs", "gate chains", "norm, activations, cell", "output layer, max, expf",
          "softmax sum, divide, context, early SGD", "bit predictions", "backward: error + hidden-error chain",
-         "backward: layer", "backward: deferred accumulation + Adam (+late SGD)", "backward: gates, clips"]
+         "backward: layer", "backward: layer-norm Adam, late SGD", "backward: gates, clips",
+         "  deferred accumulation: error vectors to registers", "  deferred accumulation: tile staging",
+         "  deferred accumulation: 100-term sums + Adam", "  Adam of the symbol columns"]
 tot = float(sum(out))
 print(f"kernel {ms:.2f} ms for {N} bytes x {S} streams = {ms * 1e3 / N:.1f} us per byte")
 for k, nme in enumerate(names):
