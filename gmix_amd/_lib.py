@@ -141,6 +141,10 @@ def lib():
     L.gmx_lstm_forward.argtypes = [vp, i32, i32, vp, vp, C.POINTER(u32)]
     L.gmx_lstm_perceive.argtypes = [vp, i32, i32]
     L.gmx_lstm_feed.argtypes = [vp, vp, u64, vp, i32, i32, vp, i32]
+    L.gmx_lstm_export.argtypes = [vp, i32, vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t)]
+    L.gmx_lstm_import.argtypes = [vp, i32, vp, C.c_size_t, vp, C.c_size_t]
+    L.gmx_lstm_copy.argtypes = [vp, i32, vp, i32]
+    L.gmx_lstm_memory_usage.argtypes = [vp, C.POINTER(u64)]
     L.gmx_debug_math_probe.argtypes = [i32, vp, vp, u64, i32]
     L.gmx_debug_math_range.argtypes = [i32, u64, u64, i32, C.POINTER(C.c_ulonglong)]
     _LIB = L
@@ -174,4 +178,5 @@ ABI_SYMBOLS = [
     "gmx_lstm_batch_destroy", "gmx_lstm_batch_ppm", "gmx_lstm_batch_bytes", "gmx_lstm_batch_predictions",
     "gmx_lstm_batch_active", "gmx_lstm_batch_contexts", "gmx_lstm_batch_upload", "gmx_lstm_batch_download",
     "gmx_lstm_batch_wait", "gmx_lstm_run", "gmx_lstm_forward", "gmx_lstm_perceive", "gmx_lstm_feed",
+    "gmx_lstm_export", "gmx_lstm_import", "gmx_lstm_copy", "gmx_lstm_memory_usage",
 ]

@@ -150,6 +150,8 @@ struct GmxLstmGateOff {   // float offsets inside a bank
   uint64_t gamma, gamma_u, gamma_m, gamma_v, beta, beta_u, beta_m, beta_v, error;  // [CP]
   uint64_t state, norm;                           // [H][CP]
   uint64_t ivar;                                  // [H]
+  uint64_t transpose;                             // [HID][CP]: NeuronLayer::transpose_, the recurrent weights as
+                                                  // the last backward pass saw them (lstm-layer.cpp:300-304)
 };
 
 struct GmxLstmDev {
@@ -164,7 +166,8 @@ struct GmxLstmDev {
   uint64_t output;                                // [H][NO]
   uint64_t input_history;                         // u32 [H]
   uint64_t probs;                                 // [NO]  LstmModel::probs_
-  uint64_t scal;                                  // u32 [16]: epoch, layer epoch, update_steps, last_byte, context, prediction bits
+  uint64_t scal;                                  // u32 [16]: epoch, layer epoch, update_steps, last_byte, context,
+                                                  // prediction bits, "a byte has been coded"
   uint64_t bank_floats;
 };
 

@@ -127,6 +127,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
   }
   L.probs[tid] = (B + dv.probs)[tid];
   uint32_t epoch = scal[0], l_epoch = scal[1], update_steps = scal[2], last_byte = scal[3], context = scal[4];
+  uint32_t coded = scal[6];
   float prediction = __uint_as_float(scal[5]);
   if (a.last_byte >= 0) last_byte = (uint32_t)a.last_byte;
   uint32_t bptt_done = 0;
@@ -309,7 +310,10 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       }
       ctx_s[n] = context;
     }
-    if (a.phases & 6u) last_byte = byte;  // the byte is known from here on
+    if (a.phases & 6u) {  // the byte is known from here on
+      last_byte = byte;
+      coded = 1;
+    }
     if (!a.learn || !(a.phases & 4u)) {
       __syncthreads();
       continue;
@@ -395,6 +399,10 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
             (B + g.beta_u)[lane] = 0.0f;
             float* up = B + g.update;
             for (int r = 0; r < NO; ++r) up[(uint64_t)r * CP + lane] = 0.0f;  // the symbol columns
+            // transpose_ (lstm-layer.cpp:300-304): only a checkpoint ever reads this copy, the
+            // chains below take the recurrent weights from the matrix itself (unchanged until Adam)
+            for (int j = 0; j < HID; ++j)
+              (B + g.transpose)[(uint64_t)j * CP + lane] = (B + g.weights)[(uint64_t)(NO + NI + j) * CP + lane];
           }
           err = L.act[wave][lane];
           nv = (B + g.norm + (uint64_t)ep * CP)[lane];
@@ -518,6 +526,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
                 m += (1.0f - beta1) * acc;
                 float v = av * beta2;
                 v += (1.0f - beta2) * acc * acc;
+                (B + go.update)[ix] = acc;  // NeuronLayer::update_ is part of the model's checkpoint
                 (B + go.m)[ix] = m;
                 (B + go.v)[ix] = v;
                 (B + go.weights)[ix] = aw - alpha * ((m / d1) / (sqrtf(v / d2 + eps)));
@@ -593,6 +602,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
     scal[3] = last_byte;
     scal[4] = context;
     scal[5] = __float_as_uint(prediction);
+    scal[6] = coded;
   }
 }
 

@@ -67,6 +67,27 @@ class LstmGroup:
     def perceive(self, byte, stream=0):
         check(self.L.gmx_lstm_perceive(self.h, stream, int(byte)), "gmx_lstm_perceive")
 
+    def export(self, stream=0):
+        """(long, short): the LSTM section of the .long file and the model's stretch of .short."""
+        nl, ns = C.c_size_t(0), C.c_size_t(0)
+        check(self.L.gmx_lstm_export(self.h, stream, None, C.byref(nl), None, C.byref(ns)), "gmx_lstm_export")
+        bl, bs = np.zeros(nl.value, np.uint8), np.zeros(ns.value, np.uint8)
+        check(self.L.gmx_lstm_export(self.h, stream, _vp(bl), C.byref(nl), _vp(bs), C.byref(ns)), "gmx_lstm_export")
+        return bl[:nl.value].tobytes(), bs[:ns.value].tobytes()
+
+    def import_(self, long_bytes, short_bytes, stream=0):
+        a = np.frombuffer(long_bytes, np.uint8).copy()
+        b = np.frombuffer(short_bytes, np.uint8).copy()
+        check(self.L.gmx_lstm_import(self.h, stream, _vp(a), len(a), _vp(b), len(b)), "gmx_lstm_import")
+
+    def copy_from(self, src, src_stream=0, stream=0):
+        check(self.L.gmx_lstm_copy(self.h, stream, src.h, src_stream), "gmx_lstm_copy")
+
+    def memory_usage(self):
+        v = C.c_uint64(0)
+        check(self.L.gmx_lstm_memory_usage(self.h, C.byref(v)), "gmx_lstm_memory_usage")
+        return v.value
+
     def feed(self, batch, n_bytes, mixer_batch=None, slot=1, mixer_ctx_col=-1, ind_batch=None, ind_ctx_col=0):
         check(self.L.gmx_lstm_feed(self.h, batch.h, n_bytes, mixer_batch.h if mixer_batch else None, slot,
                                    mixer_ctx_col, ind_batch.h if ind_batch else None, ind_ctx_col), "gmx_lstm_feed")

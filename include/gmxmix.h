@@ -295,6 +295,25 @@ int gmx_lstm_feed(gmx_lstm* l, gmx_lstm_batch* b, uint64_t n_bytes, gmx_batch* m
 int gmx_lstm_forward(gmx_lstm* l, int stream, int last_byte, const float* ppm, float* probs, uint32_t* context);
 int gmx_lstm_perceive(gmx_lstm* l, int stream, int byte);
 
+/* Persistence, byte for byte the reference's: `short` = the model's stretch of the .short file,
+ * LstmModel::WriteToDisk / ReadFromDisk (lstm-model.cpp:62-76) with Lstm::, LstmLayer:: and 3 x
+ * NeuronLayer::WriteToDisk behind it (lstm.cpp:124-158, lstm-layer.cpp:356-394, :62-122; 1 458 256
+ * bytes); `long` = the LSTM section of LongTermMemory::WriteToDisk / ReadFromDisk
+ * (long-term-memory.cpp:57-67, :151-160; 5 560 200 bytes).  Both buffers NULL: sizes only.  A bank
+ * stands at a byte boundary (GMX_ERR_STATE between gmx_lstm_forward and gmx_lstm_perceive), so
+ * top_/mid_/bot_ are written as the eighth LstmModel::Predict of the last coded byte leaves them,
+ * and import refuses (GMX_ERR_FORMAT) a checkpoint the reference took inside a byte.  After an
+ * import the bank's remembered last byte is the newest entry of input_history_; a stream that
+ * did not learn from its last byte passes it explicitly (gmx_lstm_forward).
+ * copy = LstmModel::Copy (lstm-model.cpp:78-85) + the LSTM share of LongTermMemory::Copy
+ * (long-term-memory.cpp:216-219); memory_usage = LstmModel::GetMemoryUsage (lstm-model.cpp:87-101). */
+int gmx_lstm_export(gmx_lstm* l, int stream, void* long_buf, size_t* long_bytes, void* short_buf,
+                    size_t* short_bytes);
+int gmx_lstm_import(gmx_lstm* l, int stream, const void* long_buf, size_t long_bytes, const void* short_buf,
+                    size_t short_bytes);
+int gmx_lstm_copy(gmx_lstm* dst, int dst_stream, gmx_lstm* src, int src_stream);
+int gmx_lstm_memory_usage(gmx_lstm* l, uint64_t* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -345,6 +345,83 @@ uint64_t gmxo_lstm_state_hash(const gmxo_lstm* l) {
   return h;
 }
 
+/* ---- persistence ------------------------------------------------------------------------
+ * LstmModel::WriteToDisk / ReadFromDisk (lstm-model.cpp:62-76) with everything they reach:
+ * Lstm::WriteToDisk (lstm.cpp:124-140), LstmLayer::WriteToDisk (lstm-layer.cpp:356-374) and three
+ * NeuronLayer::WriteToDisk (lstm-layer.cpp:62-91) -- the model's stretch of the `.short` file --
+ * and the LSTM section of LongTermMemory::WriteToDisk (long-term-memory.cpp:57-67) of the `.long`
+ * file.  Raw arrays in declaration order, no headers.  dir: 0 = count, 1 = write buf, 2 = read buf. */
+#define IO(ptr, len)                                        \
+  do {                                                      \
+    if (dir == 1) memcpy(buf + off, (ptr), (len));          \
+    else if (dir == 2) memcpy((ptr), buf + off, (len));     \
+    off += (len);                                           \
+  } while (0)
+
+static size_t short_walk(gmxo_lstm* l, uint8_t* buf, int dir) {
+  size_t off = 0;
+  IO(&l->top, 4);
+  IO(&l->mid, 4);
+  IO(&l->bot, 4);
+  IO(l->probs, sizeof l->probs);
+  IO(l->input_history, sizeof l->input_history);
+  IO(l->hidden, sizeof l->hidden);
+  IO(l->hidden_error, sizeof l->hidden_error);
+  IO(l->layer_input, sizeof l->layer_input);
+  IO(l->output, sizeof l->output);
+  IO(&l->epoch, 4);
+  IO(l->state, sizeof l->state);
+  IO(l->state_error, sizeof l->state_error);
+  IO(l->stored_error, sizeof l->stored_error);
+  IO(l->tanh_state, sizeof l->tanh_state);
+  IO(l->input_gate_state, sizeof l->input_gate_state);
+  IO(l->last_state, sizeof l->last_state);
+  IO(&l->l_epoch, 4);
+  IO(&l->update_steps, 8);
+  for (int g = 0; g < 3; ++g) {
+    neuron_layer* n = l->gate[g];
+    IO(n->error, sizeof n->error);
+    IO(n->ivar, sizeof n->ivar);
+    IO(n->gamma, sizeof n->gamma);
+    IO(n->gamma_u, sizeof n->gamma_u);
+    IO(n->gamma_m, sizeof n->gamma_m);
+    IO(n->gamma_v, sizeof n->gamma_v);
+    IO(n->beta, sizeof n->beta);
+    IO(n->beta_u, sizeof n->beta_u);
+    IO(n->beta_m, sizeof n->beta_m);
+    IO(n->beta_v, sizeof n->beta_v);
+    IO(n->state, sizeof n->state);
+    IO(n->update, sizeof n->update);
+    IO(n->m, sizeof n->m);
+    IO(n->v, sizeof n->v);
+    IO(n->transpose, sizeof n->transpose);
+    IO(n->norm, sizeof n->norm);
+  }
+  return off;
+}
+
+static size_t long_walk(gmxo_lstm* l, uint8_t* buf, int dir) {
+  size_t off = 0;
+  IO(l->out_layer, (size_t)H * NO * HID * 4);
+  for (int g = 0; g < 3; ++g) IO(l->gate[g]->weights, sizeof l->gate[g]->weights);
+  return off;
+}
+#undef IO
+
+/* buf == NULL: the size only */
+size_t gmxo_lstm_export_short(gmxo_lstm* l, uint8_t* buf) { return short_walk(l, buf, buf ? 1 : 0); }
+size_t gmxo_lstm_export_long(gmxo_lstm* l, uint8_t* buf) { return long_walk(l, buf, buf ? 1 : 0); }
+int gmxo_lstm_import_short(gmxo_lstm* l, const uint8_t* buf, size_t n) {
+  if (n != short_walk(l, 0, 0)) return -1;
+  short_walk(l, (uint8_t*)buf, 2);
+  return 0;
+}
+int gmxo_lstm_import_long(gmxo_lstm* l, const uint8_t* buf, size_t n) {
+  if (n != long_walk(l, 0, 0)) return -1;
+  long_walk(l, (uint8_t*)buf, 2);
+  return 0;
+}
+
 void gmxo_srand(unsigned seed) { srand(seed); }
 
 static uint64_t fnv(uint64_t h, const void* p, size_t n) {

@@ -352,6 +352,12 @@ def _lstm_lib():
         L.gmxo_lstm_perceive_byte.argtypes = [C.c_void_p, C.c_uint32]
         L.gmxo_lstm_update_steps.restype = C.c_uint64
         L.gmxo_lstm_update_steps.argtypes = [C.c_void_p]
+        for f in (L.gmxo_lstm_export_short, L.gmxo_lstm_export_long):
+            f.restype = C.c_size_t
+            f.argtypes = [C.c_void_p, C.c_void_p]
+        for f in (L.gmxo_lstm_import_short, L.gmxo_lstm_import_long):
+            f.restype = C.c_int
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L._lstm_ready = True
     return L
 
@@ -382,6 +388,24 @@ class LstmModel:
         o = np.zeros((100, 256, 51), np.float32)
         self.L.gmxo_lstm_get_output_layer(self.h, _p(o))
         return o
+
+    def export_short(self):
+        """LstmModel::WriteToDisk: the model's stretch of the .short file."""
+        buf = np.zeros(self.L.gmxo_lstm_export_short(self.h, None), np.uint8)
+        self.L.gmxo_lstm_export_short(self.h, _p(buf))
+        return buf.tobytes()
+
+    def export_long(self):
+        """The LSTM section of LongTermMemory::WriteToDisk (.long file)."""
+        buf = np.zeros(self.L.gmxo_lstm_export_long(self.h, None), np.uint8)
+        self.L.gmxo_lstm_export_long(self.h, _p(buf))
+        return buf.tobytes()
+
+    def import_state(self, long_bytes, short_bytes):
+        a = np.frombuffer(long_bytes, np.uint8).copy()
+        b = np.frombuffer(short_bytes, np.uint8).copy()
+        assert self.L.gmxo_lstm_import_long(self.h, _p(a), len(a)) == 0
+        assert self.L.gmxo_lstm_import_short(self.h, _p(b), len(b)) == 0
 
     def predict_byte(self, ppm, last_byte):
         x = np.ascontiguousarray(ppm, np.float32)
@@ -456,5 +480,7 @@ def fnv64_bytes(a):
     L = _lstm_lib()
     L.gmxo_fnv64_bytes.restype = C.c_uint64
     L.gmxo_fnv64_bytes.argtypes = [C.c_void_p, C.c_uint64]
+    if isinstance(a, (bytes, bytearray, memoryview)):
+        a = np.frombuffer(a, np.uint8)
     b = np.ascontiguousarray(a, np.uint8).reshape(-1)
     return int(L.gmxo_fnv64_bytes(_p(b), len(b)))

@@ -157,3 +157,8 @@ def test_lstm_entry_points_reject_bad_arguments():
     assert L.gmx_lstm_perceive(None, 0, 3) == -1
     assert L.gmx_lstm_feed(None, None, 1, None, 1, -1, None, 0) == -1
     assert L.gmx_lstm_bank_bytes(None) == 0
+    n = C.c_size_t(0)
+    assert L.gmx_lstm_export(None, 0, None, C.byref(n), None, C.byref(n)) == -1
+    assert L.gmx_lstm_import(None, 0, None, 0, None, 0) == -1
+    assert L.gmx_lstm_copy(None, 0, None, 0) == -1
+    assert L.gmx_lstm_memory_usage(None, None) == -1

@@ -107,7 +107,67 @@ def test_lstm_kernel_matches_reference_goldens(gpu, oracle, name):
     assert oracle.fnv64_bytes(rec.reshape(-1)) == meta["h64"]
     w, o = g.get_weights(0)
     assert oracle.fnv64_bytes(np.concatenate([o.reshape(-1).view(np.uint8), w.reshape(-1).view(np.uint8)])) == meta["long_hash"]
+    # the checkpoint the real LstmModel wrote at this point: size and hash of its .short stretch
+    # (every field, the scratch a backward pass leaves behind included), hash of its .long section
+    lng, sh = g.export(0)
+    assert len(sh) == meta["short_size"] and oracle.fnv64_bytes(sh) == meta["short_hash"]
+    assert oracle.fnv64_bytes(lng) == meta["long_hash"]
+    assert g.memory_usage() == meta["usage"]
     g.close()
+
+
+def test_lstm_checkpoint_import_export_copy(gpu, oracle):
+    """gmx_lstm_export / import / copy against the oracle's LstmModel::WriteToDisk / ReadFromDisk
+    (pinned to the reference's bytes by tests/test_oracle_lstm.py): same files at every stage, and a
+    bank restored from a file continues exactly like the model that wrote it."""
+    N, cut = 390, 230                              # two backward passes, 30 bytes into the third epoch
+    ppm, data = oracle.lstm_synth(N, seed=9, mask=127)
+    m = oracle.LstmModel()
+    g = gpu.LstmGroup(3)
+    g.set_weights(m.weights(), stream=2)
+    lng, sh = g.export(2)                          # a model nobody has used yet
+    assert lng == m.export_long() and sh == m.export_short()
+    m.run(ppm[:cut], data[:cut])
+    g.import_(m.export_long(), m.export_short(), stream=1)       # the oracle's file into a bank ...
+    lng, sh = g.export(1)
+    assert lng == m.export_long() and sh == m.export_short()     # ... and out again, byte for byte
+    g2 = gpu.LstmGroup(1)
+    g2.copy_from(g, src_stream=1)
+    assert g2.export(0) == (lng, sh)
+    pred, act, ctx = m.run(ppm[cut:], data[cut:])                # on through the third backward pass
+    for grp, st in ((g, 1), (g2, 0)):
+        b = gpu.LstmBatch(grp, N - cut)
+        b.ppm[st, :] = ppm[cut:]
+        b.bytes[st, :] = data[cut:]
+        for other in range(grp.S):
+            if other != st:
+                b.ppm[other, :] = 1.0 / 256
+                b.bytes[other, :] = 0
+        b.upload(N - cut)
+        grp.run(b, N - cut, learn=True)
+        b.download(N - cut)
+        b.wait()
+        assert np.array_equal(u32(b.predictions[st]), u32(pred)), st
+        assert np.array_equal(b.active[st], act) and np.array_equal(b.contexts[st], ctx)
+        b.close()
+        assert grp.export(st) == (m.export_long(), m.export_short())
+    # the bank written by the device goes back into the oracle and both keep agreeing
+    m2 = oracle.LstmModel(srand_seed=3)
+    m2.import_state(*g.export(1))
+    assert m2.export_short() == m.export_short()
+    # protocol and format errors
+    g.forward(ppm[0], int(data[-1]), stream=1)
+    with pytest.raises(gpu.GmxError):
+        g.export(1)                                # between Predict and Perceive: no byte boundary
+    g.perceive(int(data[0]), stream=1)
+    with pytest.raises(gpu.GmxError):
+        g.import_(lng[:-4], sh, stream=0)
+    bad = bytearray(sh)
+    bad[0:4] = (200).to_bytes(4, "little")         # top_ of a checkpoint taken inside a byte
+    with pytest.raises(gpu.GmxError):
+        g.import_(lng, bytes(bad), stream=0)
+    g.close()
+    g2.close()
 
 
 def test_lstm_per_byte_surface_for_decoding(gpu, oracle):

@@ -22,6 +22,27 @@ def test_lstm_oracle_matches_reference(oracle, name):
         assert np.array_equal(act, z["active"]) and np.array_equal(ctx, z["ctx"])
     assert h == meta["h64"]
     assert m.weights_hash(with_output_layer=True) == meta["long_hash"]
+    # LstmModel::WriteToDisk of the real model at the end of the run: size and FNV-1a of its bytes
+    # -- every field, including the scratch ones a backward pass leaves behind
+    short = m.export_short()
+    assert len(short) == meta["short_size"]
+    assert oracle.fnv64_bytes(short) == meta["short_hash"]
+    assert oracle.fnv64_bytes(m.export_long()) == meta["long_hash"]
+
+
+def test_lstm_oracle_checkpoint_round_trip(oracle):
+    """ReadFromDisk(WriteToDisk) into a fresh model continues exactly like the original."""
+    a = oracle.LstmModel()
+    ppm, data = oracle.lstm_synth(380, seed=4, mask=63)
+    a.run(ppm[:230], data[:230])
+    b = oracle.LstmModel(srand_seed=1)            # different weights until the import
+    b.import_state(a.export_long(), a.export_short())
+    assert b.export_short() == a.export_short() and b.export_long() == a.export_long()
+    b._lb, b._pr, b._cx = type(a._lb)(a._lb.value), type(a._pr)(a._pr.value), type(a._cx)(a._cx.value)
+    ra, rb = a.run(ppm[230:], data[230:]), b.run(ppm[230:], data[230:])
+    for x, y in zip(ra, rb):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+    assert a.export_short() == b.export_short() and a.export_long() == b.export_long()
 
 
 def test_lstm_learns_the_synthetic_stream(oracle):
