@@ -98,6 +98,7 @@ struct gmx_group {
   std::vector<gmx_batch*> batches; // live batches; orphaned (b->g = nullptr) when the group dies
   std::vector<struct GmxSession*> sessions;  // per stream, lazily: persistent per-bit kernels
   bool use_sessions = true;        // tests: per-bit calls as two launches instead of a session
+  bool mailbox_on_device = true;   // tests: false keeps the sessions' command blocks in pinned host memory
   bool force_general = false;      // tests: route everything through the general kernel
   bool stock_exact = false;        // tests: stock kernels use their masked forward chains only
   int single_variant = 0;          // tests/tuning: lanes per stream of the single-mixer kernel (0 = default)
@@ -986,6 +987,25 @@ extern "C" int gmx_debug_use_sessions(gmx_group* g, int on) {
 }
 
 extern "C" int gmx_debug_open_sessions(void) { return g_open_sessions.load(); }
+
+// Where the sessions keep their command blocks (on != 0: device memory when the host can store
+// there, the default; 0: pinned host memory).  Returns GMX_OK; *active (nullable) = 1 if the
+// session of `stream` exists and has its command block on the device.
+extern "C" int gmx_debug_mailbox_on_device(gmx_group* g, int on, int stream, int* active) {
+  if (!g) return GMX_ERR_INVALID;
+  if (active) {
+    GmxSession* se = (stream >= 0 && stream < (int)g->sessions.size()) ? g->sessions[stream] : nullptr;
+    *active = (se && se->mc_on_device) ? 1 : 0;
+  }
+  if ((on != 0) == g->mailbox_on_device) return GMX_OK;
+  int rc = sessions_close(g, true);
+  if (rc) return rc;
+  for (GmxSession* se : g->sessions)
+    if (se && se->fwd_live) return GMX_ERR_STATE;  // not between a forward and its learn
+  sessions_free(g);
+  g->mailbox_on_device = on != 0;
+  return GMX_OK;
+}
 
 // Wall-clock cost of n Predict+Learn pairs on `stream` through gmx_bank_forward / gmx_bank_learn
 // with made-up inputs (it trains the bank: use a scratch group).  ctx_hold = bits a context

@@ -61,34 +61,49 @@ struct GmxRunArgs {
   int32_t n_streams;          // streams this launch covers
 };
 
-// Mailbox of a per-bit session (gmx_stock_session_kernel): host-coherent pinned memory, one per
-// open session.  The host publishes a command by writing the payload, then the command word
-// (sequence number << 3 | command, release); the device answers by writing the results, then
-// the same word into done_seq.  The command word and done_seq / state sit on cache lines of
-// their own.  At most one command is outstanding.
+// Mailbox of a per-bit session (gmx_stock_session_kernel), one per open session, in two parts.
+//   GmxMbCmd   host -> device.  Lives in fine-grained DEVICE memory when the host can store there
+//              (large BAR: the wave polls and reads its payload locally, the host's stores cross
+//              PCIe once, posted), else in host-coherent pinned memory (the wave polls across PCIe).
+//   GmxMbReply device -> host, always host-coherent pinned memory (the host polls its own DRAM).
+// The host publishes a command by writing a payload slot, then the command word
+// (sequence number << 4 | payload slot << 3 | command, release); the device answers by writing
+// the results, then the same word into done_seq.  At most one command is outstanding.  Two payload
+// slots, used alternately: the payload of the forward whose learn is still to come stays intact
+// while the next one is written (LEARN*_FWD carries both; a wave restarted in between replays the
+// forward from the old slot).
 #define GMX_MB_FORWARD 1u
 #define GMX_MB_LEARN0 2u      // learn, coded bit 0
 #define GMX_MB_LEARN1 3u      // learn, coded bit 1
 #define GMX_MB_STOP 4u
+#define GMX_MB_LEARN0_FWD 5u  // learn (bit 0) of the previous forward, then forward of the slot's payload
+#define GMX_MB_LEARN1_FWD 6u
 #define GMX_MB_CMD_MASK 7u
+#define GMX_MB_SLOT_SHIFT 3
+#define GMX_MB_SEQ_SHIFT 4
 #define GMX_MB_RUNNING 0u
 #define GMX_MB_EXIT_IDLE 1u   // left after idle_ticks without a command (rows written back)
 #define GMX_MB_EXIT_STOP 2u   // left on GMX_MB_STOP
-struct GmxMailbox {
-  uint32_t cmd_seq;        // host -> device: newest command word
+struct GmxMbPayload {
+  uint32_t dec_bits;       // float bits of 0.9/pow(1e-7*steps_+0.8, 0.8) (mixer.cpp:111) for the learn
+                           // that follows this forward
+  uint32_t pad0[3];
+  uint32_t mask[4];        // active_models as a bit mask
+  uint32_t ctx[36];        // the 33 gate contexts
+  uint32_t pad1[4];
+  float pred[96];          // ShortTermMemory::predictions (90 used, zero padded)
+};
+struct GmxMbCmd {
+  uint32_t cmd_seq;        // newest command word
   uint32_t pad0[15];
-  uint32_t dec_bits;       // FORWARD: float bits of 0.9/pow(1e-7*steps_+0.8, 0.8) (mixer.cpp:111)
-                           // for the learn that follows this forward
-  uint32_t pad1[15];
-  float pred[96];          // FORWARD: ShortTermMemory::predictions (90 used, zero padded)
-  uint32_t mask[4];        // FORWARD: active_models as a bit mask
-  uint32_t ctx[36];        // FORWARD: the 33 gate contexts
-  uint32_t pad2[8];
-  uint32_t done_seq;       // device -> host: last completed command word
+  GmxMbPayload slot[2];
+};
+struct GmxMbReply {
+  uint32_t done_seq;       // last completed command word
   uint32_t state;          // GMX_MB_RUNNING / GMX_MB_EXIT_*
-  float p;                 // FORWARD result: clamped probability
-  uint32_t pad3[13];
-  float outs[48];          // FORWARD result: the 33 mixer outputs
+  float p;                 // forward result: clamped probability
+  uint32_t pad[13];
+  float outs[48];          // forward result: the 33 mixer outputs
 };
 
 // ---- Indirect models (models/indirect.cpp) -------------------

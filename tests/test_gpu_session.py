@@ -20,6 +20,7 @@ def u32(x):
 def dbg(g):
     g.L.gmx_debug_use_sessions.argtypes = [C.c_void_p, C.c_int]
     g.L.gmx_debug_open_sessions.restype = C.c_int
+    g.L.gmx_debug_mailbox_on_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
     return g.L
 
 
@@ -38,8 +39,10 @@ def per_bit(g, rec, t0, t1, stream=0, hook=None):
     return P, O
 
 
-@pytest.mark.parametrize("sessions", [True, False])
+@pytest.mark.parametrize("sessions", ["device", "host", False])
 def test_per_bit_equals_oracle_with_interruptions(gpu, oracle, sessions):
+    """sessions: where the session's command block lives (device memory written through the BAR /
+    pinned host memory), or False for two kernel launches per bit."""
     topo = topology.stock(90)
     T = 1500
     rec = oracle.synth(90, 33, T, seed=4242, ctx_mode=3, ctx_mod=5, zero_mod=7, bit_mode=1)
@@ -48,6 +51,7 @@ def test_per_bit_equals_oracle_with_interruptions(gpu, oracle, sessions):
     g = gpu.MixerGroup(topo, 2)
     L = dbg(g)
     assert L.gmx_debug_use_sessions(g.h, 1 if sessions else 0) == 0
+    assert L.gmx_debug_mailbox_on_device(g.h, 0 if sessions == "host" else 1, 0, None) == 0
     exports = []
 
     def hook(t, where):
@@ -62,6 +66,10 @@ def test_per_bit_equals_oracle_with_interruptions(gpu, oracle, sessions):
             assert g.memory_usage(3) > 0
 
     P, O = per_bit(g, rec, 0, T, stream=0, hook=hook)
+    on_dev = C.c_int(-1)
+    assert L.gmx_debug_mailbox_on_device(g.h, 0 if sessions == "host" else 1, 0, C.byref(on_dev)) == 0
+    if sessions == "host":
+        assert on_dev.value == 0
     assert np.array_equal(u32(O), u32(o_ref))
     assert np.array_equal(u32(P), u32(p_ref))
     assert g.export(0) == (ob.export_long(), ob.export_short())
@@ -150,18 +158,24 @@ def test_per_bit_latency_report(gpu, capsys):
     """Not a parity test: records what a Predict+Learn pair costs through the C ABI."""
     topo = topology.stock(90)
     out = {}
-    for sessions in (1, 0):
+    where = {}
+    for sessions in (1, 2, 0):           # 1: command block on the device if the host can write there, 2: pinned host
         g = gpu.MixerGroup(topo, 1)
         L = dbg(g)
         L.gmx_debug_per_bit_latency.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
-        assert L.gmx_debug_use_sessions(g.h, sessions) == 0
+        assert L.gmx_debug_use_sessions(g.h, 1 if sessions else 0) == 0
+        assert L.gmx_debug_mailbox_on_device(g.h, 0 if sessions == 2 else 1, 0, None) == 0
         us = C.c_double()
         assert L.gmx_debug_per_bit_latency(g.h, 0, 500, 8, C.byref(us)) == 0
         for hold in (1, 8):
             assert L.gmx_debug_per_bit_latency(g.h, 0, 4000, hold, C.byref(us)) == 0
             out[sessions, hold] = us.value
+        on_dev = C.c_int(0)
+        L.gmx_debug_mailbox_on_device(g.h, 0 if sessions == 2 else 1, 0, C.byref(on_dev))
+        where[sessions] = "device memory" if on_dev.value else "pinned host memory"
         g.close()
     with capsys.disabled():
-        print(f"\n[per-bit Predict+Learn, C ABI] session: {out[1, 1]:.1f} us/bit (new rows every bit), "
-              f"{out[1, 8]:.1f} us/bit (contexts held 8 bits); two launches: {out[0, 1]:.1f} / {out[0, 8]:.1f} us/bit")
+        print(f"\n[per-bit Predict+Learn, C ABI] session, commands in {where[1]}: {out[1, 1]:.1f} us/bit (new rows "
+              f"every bit), {out[1, 8]:.1f} us/bit (contexts held 8 bits); in {where[2]}: {out[2, 1]:.1f} / "
+              f"{out[2, 8]:.1f}; two launches: {out[0, 1]:.1f} / {out[0, 8]:.1f} us/bit")
     assert out[1, 8] < out[0, 8]
