@@ -99,6 +99,13 @@ struct ShortTermMemory {
   int num_layer1_mixers = 0;
   float final_mixer_output = 0;
   std::vector<Mixer*> mixer_index_to_model_ptr;
+  // what the Indirect and LSTM mirrors of gmx_models.h read and write (short-term-memory.h:67-74,
+  // :127, :161); BasicContexts / ModPPMD keep them up to date in the reference
+  int recent_bits = 1;
+  unsigned int bit_context = 0;
+  unsigned int last_byte = 0;
+  std::valarray<float> ppm_predictions = std::valarray<float>(1.0f / 256, 256);
+  unsigned int lstm_prediction_context = 0;
 };
 
 // Owns the device-resident replacement of LongTermMemory::mixers for one Predictor.
