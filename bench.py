@@ -174,7 +174,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": ("gmx_single_kernel" if topo.n_mixers == 1 else
-                                    "gmx_stock_kernel" if args.config == "stock" else "gmx_bank_kernel"),
+                                    "gmx_stock_kernel" if args.config == "stock" else ("gmx_wide_kernel" if args.config == "synth3" else "gmx_bank_kernel")),
                          "kernel_ms_avg": avg_ms,
                          "algorithmic_bytes_per_bit": bytes_per_bit,
                          "bytes_per_launch": bytes_per_launch},

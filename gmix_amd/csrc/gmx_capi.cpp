@@ -44,6 +44,8 @@ hipError_t gmx_launch_stock_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* a
                                    unsigned lds_bytes, int has_mask, hipStream_t stream);
 hipError_t gmx_launch_single_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_inputs,
                                     int variant, hipStream_t stream);
+hipError_t gmx_launch_wide_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_streams, int has_mask,
+                                  hipStream_t stream);
 hipError_t gmx_launch_synth_kernel(const GmxSynthArgs* args, hipStream_t stream);
 hipError_t gmx_launch_init_scal(uint8_t* banks, uint64_t bank_bytes, uint64_t scal_off, int m,
                                 int n_streams, hipStream_t stream);
@@ -497,8 +499,15 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
   // registers (gmx_stock.hip); it only needs the small part of the LDS image.
   const bool stock = g->topo.n == 90 && g->topo.l0 == 24 && g->topo.l1 == 8 && g->topo.n_skip == 1 &&
                      g->topo.has_final && g->topo.mx[23].stride == 128 && !g->force_general;
+  // The 256-input 24/8/1 bank (BASELINE configs[2]) likewise, two lanes per layer-0 row
+  // (gmx_wide.hip); batched Predict(+Learn) only.
+  const bool wide = g->topo.n == 256 && g->topo.l0 == 24 && g->topo.l1 == 8 && g->topo.n_skip == 1 &&
+                    g->topo.has_final && g->topo.mx[23].stride == 288 && (mode & GMX_MODE_PREDICT) &&
+                    !(mode & GMX_MODE_LATCH) && !g->force_general;
   if (single)
     HIPCHK(gmx_launch_single_kernel(g->topo_dev, &a, g->topo.n, g->single_variant, g->stream));
+  else if (wide)
+    HIPCHK(gmx_launch_wide_kernel(g->topo_dev, &a, ns, a.mask != nullptr, g->stream));
   else if (stock)
     HIPCHK(gmx_launch_stock_kernel(g->topo_dev, &a, ns, (g->topo.lds_misc + 256u) * 4u,
                                    a.mask != nullptr, g->stream));
