@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=3072,
+    ap.add_argument("--streams", type=int, default=None,
                     help="independent streams per GPU (each owns a dense 64.5 MiB gate table: 3072 = 194 GiB of HBM)")
     ap.add_argument("--bits", type=int, default=512, help="bits per stream per step")
     ap.add_argument("--config", default="single")
@@ -104,6 +104,8 @@ def main():
 
     import gmix_amd
     topo, workload = make_topology(args.config)
+    if args.streams is None:  # what fills the chip for the shape: one wave per SIMD for the 3-layer banks
+        args.streams = 3072 if args.config == "single" else 1024
     S, T = args.streams, args.bits
     steps = args.steps if args.steps is not None else max(1, -(-100_000_000 // (S * T)))  # 10^8 bits
 

@@ -43,6 +43,22 @@ constexpr int kQ = kHalf / 4;  // 36 register quads per lane
 constexpr int kQS = 9;         // quads of a layer-1 / final row that can hold weights (<= 33 of 64 stored floats)
 constexpr int kQB = (kN - kHalf) / 4;  // 28: quads of the upper half that face inputs; cascade weights follow
 constexpr int kFinLane = 56;
+// Staging image of the rows in LDS (floats): 48 layer-0 halves `kPitch` apart -- 144 floats + 4, so
+// that the 16 lanes of a ds_read_b128 group, each reading its own row at the same quad, hit 16
+// different bank quads -- then the 9 small rows `kPitchS` apart.
+constexpr int kPitch = kHalf + 4, kPitchS = 4 * kQS + 4;
+constexpr int kStageSmall = 2 * kL0 * kPitch;
+constexpr int kStageFloats = kStageSmall + (kL1 + 1) * kPitchS;
+// staging slot of lane h's row piece, its length in 16-byte lanes (0: lane h holds no row)
+__host__ __device__ constexpr int stage_off(int h) {
+  return h < kL0 ? h * kPitch
+         : h < 32 ? kStageSmall + (h - kL0) * kPitchS
+         : h < 32 + kL0 ? (kL0 + h - 32) * kPitch
+         : h == kFinLane ? kStageSmall + kL1 * kPitchS : 0;
+}
+__host__ __device__ constexpr int stage_lanes(int h) {
+  return (h < kL0 || (h >= 32 && h < 32 + kL0)) ? kQ : ((h < 32 || h == kFinLane) ? kQS : 0);
+}
 
 __device__ __forceinline__ void wide_ld16(gmx_f4& d, const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
@@ -53,6 +69,35 @@ __device__ __forceinline__ void wide_ld4(uint32_t& d, const void* p) {
 __device__ __forceinline__ void wide_ld1(uint32_t& d, const void* p) {
   asm volatile("global_load_ubyte %0, %1, off" : "=v"(d) : "v"(p) : "memory");
 }
+__device__ __forceinline__ uint32_t readlane_u(uint32_t v, int l) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+__device__ __forceinline__ uint32_t wide_lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// One coalesced piece of a row, HBM -> LDS without a VGPR round trip: the lanes of `mask` move 16
+// bytes each from sbase + voff to LDS[lds_byte + 16 * lane] (LDS base in M0, saved and restored).
+// An empty mask issues nothing.
+__device__ __forceinline__ void wide_dma16(uint64_t sbase, uint32_t voff, uint32_t lds_byte, uint64_t mask) {
+  uint64_t sv;
+  uint32_t sm0;
+  asm volatile(
+      "s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %3, %2\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %0"
+      : "=&s"(sv), "=&s"(sm0)
+      : "s"(sbase), "v"(voff), "s"(mask), "s"(lds_byte)
+      : "memory");
+}
+// ... and back: the lanes of `mask` store 16 bytes each to sbase + voff.
+__device__ __forceinline__ void wide_st16(uint64_t sbase, uint32_t voff, const gmx_f4& v, uint64_t mask) {
+  uint64_t sv;
+  asm volatile(
+      "s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\t"
+      "global_store_dwordx4 %2, %3, %1\n\ts_mov_b64 exec, %0"
+      : "=&s"(sv)
+      : "s"(sbase), "v"(voff), "v"(v), "s"(mask)
+      : "memory");
+}
 __device__ __forceinline__ float readlane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
@@ -61,9 +106,10 @@ __device__ __forceinline__ float el(const gmx_f4& v, int e) { return e == 0 ? v.
 }  // namespace
 
 template <bool HAS_MASK>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
   __shared__ __attribute__((aligned(16))) float xin[kN];
+  __shared__ __attribute__((aligned(16))) float stage[kStageFloats];
   __shared__ uint64_t s_tab[32];
   const int lane = threadIdx.x;
   const int rec = a.rec_base + (int)blockIdx.x;
@@ -114,17 +160,45 @@ gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
   uint64_t rs = 0;      // MixerData::steps of the resident row (long-term-memory.h:29)
   bool dirty = false;
 
+  // Rows travel between HBM and the registers through the staging image, so that every global
+  // access is a coalesced run of 16-byte lanes (lane-private 16-byte accesses cost the texture
+  // path four tag look-ups per 64-byte line, and four partial writes: measured, it was 70% busy).
+  float* const my_stage = stage + stage_off(0) + (is_l0 ? (half * kL0 + li) * kPitch
+                                                        : kStageSmall + (is_fin ? kL1 : (li - kL0)) * kPitchS);
+  const uint32_t stage_base = wide_lds_addr(stage);
+  const uint32_t lane16 = (uint32_t)lane * 16u;
   auto evict = [&](bool ev) {
+    const uint64_t em = __ballot(ev);
+    if (em == 0) return;
+    const uint64_t dst = (uint64_t)(w_tab + (uint64_t)tag * row_bytes);
+    const uint32_t dlo = (uint32_t)dst, dhi = (uint32_t)(dst >> 32);
     if (ev) {
-      uint8_t* dst = w_tab + (uint64_t)tag * row_bytes;
 #pragma unroll
-      for (int q = 0; q < kQS; ++q) *(gmx_f4*)(dst + 16 * q) = w[q];
+      for (int q = 0; q < kQS; ++q) *(gmx_f4*)(my_stage + 4 * q) = w[q];
       if (owner) rs_tab[tag] = rs;
     }
     if (ev && is_l0) {
-      uint8_t* dst = w_tab + (uint64_t)tag * row_bytes;
 #pragma unroll
-      for (int q = kQS; q < kQ; ++q) *(gmx_f4*)(dst + 16 * q) = w[q];
+      for (int q = kQS; q < kQ; ++q) *(gmx_f4*)(my_stage + 4 * q) = w[q];
+    }
+#pragma unroll
+    for (int h = 0; h <= kFinLane; ++h) {
+      if (stage_lanes(h) == 0) continue;
+      const uint64_t m = ((em >> h) & 1u) ? ((1ull << stage_lanes(h)) - 1ull) : 0ull;
+      const uint64_t sb = ((uint64_t)readlane_u(dhi, h) << 32) | readlane_u(dlo, h);
+      const gmx_f4 v = *(const gmx_f4*)(stage + stage_off(h) + 4 * (lane < stage_lanes(h) ? lane : 0));
+      wide_st16(sb, lane16, v, m);
+    }
+  };
+  // the rows of the lanes in `nm` (non-empty) from HBM into the staging image
+  auto fetch = [&](uint64_t nm, uint64_t src) {
+    const uint32_t slo = (uint32_t)src, shi = (uint32_t)(src >> 32);
+#pragma unroll
+    for (int h = 0; h <= kFinLane; ++h) {
+      if (stage_lanes(h) == 0) continue;
+      const uint64_t m = ((nm >> h) & 1u) ? ((1ull << stage_lanes(h)) - 1ull) : 0ull;
+      const uint64_t sb = ((uint64_t)readlane_u(shi, h) << 32) | readlane_u(slo, h);
+      wide_dma16(sb, lane16, stage_base + (uint32_t)stage_off(h) * 4u, m);
     }
   };
 
@@ -156,20 +230,25 @@ gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
     const uint32_t row = all_pow2 ? (ctx & (d.table_size - 1u)) : (ctx % d.table_size);
     const bool need = act && row != tag;
     evict(need && dirty);
-    if (need) {
-      const uint8_t* src = w_tab + (uint64_t)row * row_bytes;
+    const uint64_t nm = __ballot(need);
+    if (nm) {
+      // the staging image is free again once the write-back has read it (its ds_reads are done:
+      // their data went into the stores above)
+      fetch(nm, (uint64_t)(w_tab + (uint64_t)row * row_bytes));
+      if (need) rs = rs_tab[row];
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(rs) : : "memory");
+      if (need) {
 #pragma unroll
-      for (int q = 0; q < kQS; ++q) w[q] = *(const gmx_f4*)(src + 16 * q);
-      rs = rs_tab[row];
-      tag = row;
-      dirty = false;
-    }
-    if (need && is_l0) {
-      const uint8_t* src = w_tab + (uint64_t)row * row_bytes;
+        for (int q = 0; q < kQS; ++q) w[q] = *(const gmx_f4*)(my_stage + 4 * q);
+        tag = row;
+        dirty = false;
+      }
+      if (need && is_l0) {
 #pragma unroll
-      for (int q = kQS; q < kQ; ++q) w[q] = *(const gmx_f4*)(src + 16 * q);
+        for (int q = kQS; q < kQ; ++q) w[q] = *(const gmx_f4*)(my_stage + 4 * q);
+      }
     }
-    request(t + 1);  // behind this bit's row traffic, a whole bit ahead of its use
+    request(t + 1);  // a whole bit ahead of its use
 
     // ---- the blackboard of this bit into LDS ----------------------------------------------
     *(gmx_f4*)(xin + 4 * lane) = xv;
