@@ -94,6 +94,9 @@ struct gmx_group {
     bool busy = false;
   } decay[2];
   hipStream_t copy_stream = nullptr;  // uploads of the decay tables, beside the running kernel
+  // record batches travel on streams of their own, beside the running kernel (BASELINE configs[3]:
+  // "pinned hipMemcpyAsync double-buffered host->device probability batches"); events order them
+  hipStream_t up_stream = nullptr, down_stream = nullptr;
   unsigned run_seq = 0;
   hipEvent_t tm0 = nullptr, tm1 = nullptr;  // gmx_group_timer_*
   gmx_batch* one = nullptr;        // 1-bit batch (one record per stream) of the per-bit surface
@@ -130,6 +133,11 @@ struct gmx_batch {
   uint8_t* h_bits = nullptr;
   float* h_p = nullptr;
   float* h_out = nullptr;
+  // ordering of this batch's transfers against the kernels that use its device arrays
+  hipEvent_t ev_up = nullptr;    // behind the newest upload (on the group's upload stream)
+  hipEvent_t ev_dev = nullptr;   // behind the newest device-side use (on the group's stream)
+  hipEvent_t ev_down = nullptr;  // behind the newest download (on the group's download stream)
+  bool up_rec = false, dev_rec = false, down_rec = false;
 };
 
 // per-bit sessions (gmx_session.inc)
@@ -270,6 +278,7 @@ static int build_topology(const gmx_topology* t, GmxTopoDev* o) {
 
 static void batch_free(gmx_batch* b);
 static int batch_alloc(gmx_batch** out, gmx_group* g, int S, uint64_t max_bits, unsigned flags);
+static int batch_note_device_use(gmx_batch* b);
 
 extern "C" int gmx_group_create(gmx_group** out, const gmx_topology* topo, int n_streams, int device) {
   if (!out || n_streams < 1) return GMX_ERR_INVALID;
@@ -345,6 +354,14 @@ extern "C" void gmx_group_destroy(gmx_group* g) {
     if (d.ready) (void)hipEventDestroy(d.ready);
   }
   if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
+  if (g->up_stream) {
+    (void)hipStreamSynchronize(g->up_stream);
+    (void)hipStreamDestroy(g->up_stream);
+  }
+  if (g->down_stream) {
+    (void)hipStreamSynchronize(g->down_stream);
+    (void)hipStreamDestroy(g->down_stream);
+  }
   if (g->tm0) (void)hipEventDestroy(g->tm0);
   if (g->tm1) (void)hipEventDestroy(g->tm1);
   if (g->ev0) (void)hipEventDestroy(g->ev0);
@@ -490,6 +507,7 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
   a.stream_base = s0;
   a.rec_base = rec0;
   a.n_streams = ns;
+  if (b->down_rec) HIPCHK(hipStreamWaitEvent(g->stream, b->ev_down, 0));  // p of the previous run is out
   if (kernel_ms) HIPCHK(hipEventRecord(g->ev0, g->stream));
   // Banks that are a single layer-0 mixer take the register-resident throughput kernel
   // (gmx_single.hip); everything else, and every per-bit call, the general kernel.
@@ -517,6 +535,10 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
                                   g->topo.mx[g->topo.l0 - 1].stride, g->stream));
   HIPCHK(hipEventRecord(dec->done, g->stream));
   dec->busy = true;
+  if (b->ev_dev) {
+    int rcn = batch_note_device_use(b);
+    if (rcn) return rcn;
+  }
   if (kernel_ms) {
     HIPCHK(hipEventRecord(g->ev1, g->stream));
     HIPCHK(hipEventSynchronize(g->ev1));
@@ -533,6 +555,8 @@ static void batch_free(gmx_batch* b) {
   if (b->g) {
     (void)hipSetDevice(b->g->device);
     if (b->g->stream) (void)hipStreamSynchronize(b->g->stream);
+    if (b->g->up_stream) (void)hipStreamSynchronize(b->g->up_stream);
+    if (b->g->down_stream) (void)hipStreamSynchronize(b->g->down_stream);
     auto& v = b->g->batches;
     v.erase(std::remove(v.begin(), v.end(), b), v.end());
   }
@@ -543,6 +567,9 @@ static void batch_free(gmx_batch* b) {
   void* hv[] = {b->h_pred, b->h_mask, b->h_ctx, b->h_bits, b->h_p, b->h_out};
   for (void* p : hv)
     if (p) (void)hipHostFree(p);
+  hipEvent_t evs[] = {b->ev_up, b->ev_dev, b->ev_down};
+  for (hipEvent_t e : evs)
+    if (e) (void)hipEventDestroy(e);
   delete b;
 }
 
@@ -573,6 +600,9 @@ static int batch_alloc(gmx_batch** out, gmx_group* g, int S, uint64_t max_bits, 
   BCHK(hipMalloc((void**)&b->d_bits, R));
   BCHK(hipMalloc((void**)&b->d_p, R * sizeof(float)));
   if (flags & GMX_BATCH_OUTPUTS) BCHK(hipMalloc((void**)&b->d_out, R * t.m * sizeof(float)));
+  BCHK(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
+  BCHK(hipEventCreateWithFlags(&b->ev_dev, hipEventDisableTiming));
+  BCHK(hipEventCreateWithFlags(&b->ev_down, hipEventDisableTiming));
 #undef BCHK
   g->batches.push_back(b);
   *out = b;
@@ -627,47 +657,77 @@ extern "C" const float* gmx_batch_outputs(gmx_batch* b) {
 
 // Copy the first n_bits records of every stream (rows of a [S][max_bits][w] array).
 static hipError_t copy_rows(void* dst, const void* src, size_t elem_bytes, size_t w, gmx_batch* b,
-                            uint64_t n_bits, hipMemcpyKind kind) {
+                            uint64_t n_bits, hipMemcpyKind kind, hipStream_t st) {
   const size_t pitch = (size_t)b->max_bits * w * elem_bytes;
   const size_t width = (size_t)n_bits * w * elem_bytes;
   if (n_bits == b->max_bits || b->S == 1)
-    return hipMemcpyAsync(dst, src, b->S == 1 ? width : pitch * b->S, kind, b->g->stream);
-  return hipMemcpy2DAsync(dst, pitch, src, pitch, width, (size_t)b->S, kind, b->g->stream);
+    return hipMemcpyAsync(dst, src, b->S == 1 ? width : pitch * b->S, kind, st);
+  return hipMemcpy2DAsync(dst, pitch, src, pitch, width, (size_t)b->S, kind, st);
 }
 
+// Device-side work on the group's stream has just been queued that reads or writes b's arrays.
+static int batch_note_device_use(gmx_batch* b) {
+  HIPCHK(hipEventRecord(b->ev_dev, b->g->stream));
+  b->dev_rec = true;
+  return GMX_OK;
+}
+
+// The copies run on the group's upload stream: behind the last kernel that used this batch's
+// arrays, beside whatever else the group's stream is running (the kernel of ANOTHER batch, in a
+// double-buffered loop).  Everything queued on the group's stream after this call sees the records.
 extern "C" int gmx_batch_upload(gmx_batch* b, uint64_t n_bits) {
   if (!b || !b->g || n_bits > b->max_bits) return GMX_ERR_INVALID;
   if (n_bits == 0) return GMX_OK;
-  const GmxTopoDev& t = b->g->topo;
-  HIPCHK(hipSetDevice(b->g->device));
+  gmx_group* g = b->g;
+  const GmxTopoDev& t = g->topo;
+  HIPCHK(hipSetDevice(g->device));
   if (!gmx_batch_predictions(b) || !gmx_batch_contexts(b) || !gmx_batch_bits(b)) return GMX_ERR_NOMEM;
-  HIPCHK(copy_rows(b->d_pred, b->h_pred, 4, t.n_pad, b, n_bits, hipMemcpyHostToDevice));
-  if (b->flags & GMX_BATCH_MASK) {
-    if (!gmx_batch_active_mask(b)) return GMX_ERR_NOMEM;
-    HIPCHK(copy_rows(b->d_mask, b->h_mask, 4, t.mask_words, b, n_bits, hipMemcpyHostToDevice));
-  }
-  HIPCHK(copy_rows(b->d_ctx, b->h_ctx, 4, t.m, b, n_bits, hipMemcpyHostToDevice));
-  HIPCHK(copy_rows(b->d_bits, b->h_bits, 1, 1, b, n_bits, hipMemcpyHostToDevice));
+  if ((b->flags & GMX_BATCH_MASK) && !gmx_batch_active_mask(b)) return GMX_ERR_NOMEM;
+  if (!g->up_stream) HIPCHK(hipStreamCreateWithFlags(&g->up_stream, hipStreamNonBlocking));
+  hipStream_t st = g->up_stream;
+  if (b->dev_rec) HIPCHK(hipStreamWaitEvent(st, b->ev_dev, 0));
+  HIPCHK(copy_rows(b->d_pred, b->h_pred, 4, t.n_pad, b, n_bits, hipMemcpyHostToDevice, st));
+  if (b->flags & GMX_BATCH_MASK)
+    HIPCHK(copy_rows(b->d_mask, b->h_mask, 4, t.mask_words, b, n_bits, hipMemcpyHostToDevice, st));
+  HIPCHK(copy_rows(b->d_ctx, b->h_ctx, 4, t.m, b, n_bits, hipMemcpyHostToDevice, st));
+  HIPCHK(copy_rows(b->d_bits, b->h_bits, 1, 1, b, n_bits, hipMemcpyHostToDevice, st));
+  HIPCHK(hipEventRecord(b->ev_up, st));
+  b->up_rec = true;
+  HIPCHK(hipStreamWaitEvent(g->stream, b->ev_up, 0));
   return GMX_OK;
 }
 
+// Behind everything queued on the group's stream so far, on the group's download stream.
 extern "C" int gmx_batch_download(gmx_batch* b, uint64_t n_bits) {
   if (!b || !b->g || n_bits > b->max_bits) return GMX_ERR_INVALID;
   if (n_bits == 0) return GMX_OK;
-  const GmxTopoDev& t = b->g->topo;
-  HIPCHK(hipSetDevice(b->g->device));
+  gmx_group* g = b->g;
+  const GmxTopoDev& t = g->topo;
+  HIPCHK(hipSetDevice(g->device));
   if (!gmx_batch_p(b)) return GMX_ERR_NOMEM;
-  HIPCHK(copy_rows(b->h_p, b->d_p, 4, 1, b, n_bits, hipMemcpyDeviceToHost));
-  if (b->flags & GMX_BATCH_OUTPUTS) {
-    if (!gmx_batch_outputs(b)) return GMX_ERR_NOMEM;
-    HIPCHK(copy_rows(b->h_out, b->d_out, 4, t.m, b, n_bits, hipMemcpyDeviceToHost));
-  }
+  if ((b->flags & GMX_BATCH_OUTPUTS) && !gmx_batch_outputs(b)) return GMX_ERR_NOMEM;
+  if (!g->down_stream) HIPCHK(hipStreamCreateWithFlags(&g->down_stream, hipStreamNonBlocking));
+  hipStream_t st = g->down_stream;
+  int rc = batch_note_device_use(b);
+  if (rc) return rc;
+  HIPCHK(hipStreamWaitEvent(st, b->ev_dev, 0));
+  HIPCHK(copy_rows(b->h_p, b->d_p, 4, 1, b, n_bits, hipMemcpyDeviceToHost, st));
+  if (b->flags & GMX_BATCH_OUTPUTS)
+    HIPCHK(copy_rows(b->h_out, b->d_out, 4, t.m, b, n_bits, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(b->ev_down, st));
+  b->down_rec = true;
   return GMX_OK;
 }
 
+// The host waits for THIS batch's queued work: its upload, the device work that used it, its
+// download.  (Work on other batches of the group keeps running.)
 extern "C" int gmx_batch_wait(gmx_batch* b) {
   if (!b || !b->g) return GMX_ERR_INVALID;
-  return gmx_group_sync(b->g);
+  HIPCHK(hipSetDevice(b->g->device));
+  if (b->up_rec) HIPCHK(hipEventSynchronize(b->ev_up));
+  if (b->dev_rec) HIPCHK(hipEventSynchronize(b->ev_dev));
+  if (b->down_rec) HIPCHK(hipEventSynchronize(b->ev_down));
+  return GMX_OK;
 }
 
 extern "C" int gmx_batch_fill_synthetic(gmx_batch* b, uint64_t n_bits, uint64_t seed,
@@ -706,8 +766,9 @@ extern "C" int gmx_batch_fill_synthetic(gmx_batch* b, uint64_t n_bits, uint64_t 
   a.bit_mode = bit_mode;
   a.ctx_mod = ctx_mod;
   a.zero_mod = zero_mod;
+  if (b->up_rec) HIPCHK(hipStreamWaitEvent(b->g->stream, b->ev_up, 0));
   HIPCHK(gmx_launch_synth_kernel(&a, b->g->stream));
-  return GMX_OK;
+  return batch_note_device_use(b);
 }
 
 extern "C" int gmx_group_run(gmx_group* g, gmx_batch* b, uint64_t n_bits, int learn, float* kernel_ms) {

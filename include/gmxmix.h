@@ -131,9 +131,14 @@ uint32_t* gmx_batch_contexts(gmx_batch* b);
 uint8_t* gmx_batch_bits(gmx_batch* b);
 const float* gmx_batch_p(gmx_batch* b);
 const float* gmx_batch_outputs(gmx_batch* b);   /* NULL without GMX_BATCH_OUTPUTS */
+/* Transfers run on streams of their own, ordered by events against the kernels that use the
+ * batch: an upload starts when the last run of THIS batch is done and overlaps whatever runs on
+ * other batches (double buffering: run(A); upload(B); run(B); download(A); wait(A); refill A ...);
+ * everything queued on the group after gmx_batch_upload returns sees the new records.  A download
+ * follows everything queued on the group so far.  wait = this batch's upload, runs and download. */
 int gmx_batch_upload(gmx_batch* b, uint64_t n_bits);    /* async H2D of the first n_bits of every stream */
 int gmx_batch_download(gmx_batch* b, uint64_t n_bits);  /* async D2H of p (and outputs) */
-int gmx_batch_wait(gmx_batch* b);                       /* host waits for the batch's queued work */
+int gmx_batch_wait(gmx_batch* b);                       /* host waits for this batch's queued work */
 /* Fill the DEVICE record buffers with the next n_bits of the synthetic stream of
  * BASELINE.json configs[1] (xorshift64; logits on the [-4,4] grid, 32-bit contexts, random
  * bits), generated on the GPU.  restart != 0 re-seeds stream s with
