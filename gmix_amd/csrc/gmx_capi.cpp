@@ -1023,7 +1023,7 @@ extern "C" int gmx_bank_memory_usage(gmx_group* g, int stream, int mixer, uint64
 // ---- test probes (device math against host math; not part of the product surface) --------
 extern "C" int gmx_debug_single_variant(gmx_group* g, int lanes_per_stream) {
   if (!g || (lanes_per_stream != 0 && lanes_per_stream != 16 && lanes_per_stream != 32 &&
-             lanes_per_stream != 64))
+             lanes_per_stream != 64 && lanes_per_stream != 165 && lanes_per_stream != 325))
     return GMX_ERR_INVALID;
   g->single_variant = lanes_per_stream;
   return GMX_OK;

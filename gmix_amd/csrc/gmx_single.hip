@@ -410,6 +410,8 @@ extern "C" hipError_t gmx_launch_single_kernel(const GmxTopoDev* tp_dev, const G
   // Measured on MI355X (2048-3584 streams of 256 inputs): 16 and 32 lanes per stream run
   // within 2% of each other, 64 lanes (twice the waves, same issue-bound SIMDs) 10-15% behind.
   const bool full = n_inputs == 256;
+  if (variant == 165) return launch_k<16, 4, 5>(tp_dev, a, full, stream);  // tuning: one more slot in flight
+  if (variant == 325) return launch_k<32, 2, 5>(tp_dev, a, full, stream);
   if (variant == 64) return launch_k<64, 1, 6>(tp_dev, a, full, stream);
   if (variant == 32) return launch_k<32, 2, 4>(tp_dev, a, full, stream);
   return launch_k<16, 4, 4>(tp_dev, a, full, stream);
