@@ -336,24 +336,34 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
           for (int j = tid; j < LIN; j += 256) L.xin[j] = (B + dv.layer_input + (uint64_t)ep * LINP)[j];
         }
         __syncthreads();
-        if (tid < NC) {
-          const float* ol = out_layer + ((uint64_t)ep * HID + tid) * NO;
-          float he = L.herr[tid];
-#pragma unroll 1
-          for (int i0 = 0; i0 < NO; i0 += 4 * GMX_LSTM_Q) {
-            float4 ov[GMX_LSTM_Q];
+        {
+          // hidden_error_[j] += sum_i lstm_output_layer[ep][i][j] * error[i], i = 0..255 in order
+          // (lstm.cpp:61-69).  Four lanes share a row j of the [hidden][symbol] slab: lane s holds
+          // columns 16m + 4s .. + 3, so a load instruction moves whole 64-byte lines and all 16 of
+          // a lane are in flight at once (one memory latency per epoch instead of four).  The sum
+          // walks the four lanes in column order: acc = quad_rotate(acc) + p executed by all of
+          // them, lane s holding the true prefix at step s.
+          const int j = tid >> 2, sq = tid & 3;
+          const int jr = j < NC ? j : 0;  // threads 200.. shadow row 0 and do not store
+          const float* ol = out_layer + ((uint64_t)ep * HID + jr) * NO + 4 * sq;
+          float4 ov[GMX_LSTM_Q];
 #pragma unroll
-            for (int u = 0; u < GMX_LSTM_Q; ++u) ov[u] = *(const float4*)(ol + i0 + 4 * u);
+          for (int m = 0; m < GMX_LSTM_Q; ++m) ov[m] = *(const float4*)(ol + 16 * m);
+          float he = L.herr[jr];  // picked up by lane 0 through the first rotate
 #pragma unroll
-            for (int u = 0; u < GMX_LSTM_Q; ++u) {
-              const float4 ev = *(const float4*)(L.err + i0 + 4 * u);
-              he += ov[u].x * ev.x;
-              he += ov[u].y * ev.y;
-              he += ov[u].z * ev.z;
-              he += ov[u].w * ev.w;
+          for (int m = 0; m < GMX_LSTM_Q; ++m) {
+            const float4 ev = *(const float4*)(L.err + 16 * m + 4 * sq);
+            const float px = ov[m].x * ev.x, py = ov[m].y * ev.y, pz = ov[m].z * ev.z, pw = ov[m].w * ev.w;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              he = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(he), 0x93, 0xf, 0xf, false)) + px;
+              he += py;
+              he += pz;
+              he += pw;
             }
           }
-          L.herr[tid] = he;
+          __syncthreads();  // every lane has read its herr before the last lanes overwrite it
+          if (sq == 3 && j < NC) L.herr[j] = he;
         }
         __syncthreads();
         const uint32_t prev_epoch = ep == 0 ? H - 1 : ep - 1;
