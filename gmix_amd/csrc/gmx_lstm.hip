@@ -26,6 +26,7 @@
 // specification.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gmx_internal.h"
 #include "gmx_math.h"
@@ -34,6 +35,12 @@
 // workgroups per CU (GMX_LSTM_BLOCKS): shorter stretches cost latency per byte, fewer registers
 // let more streams run at once.  Measured at 4096 streams: 2 workgroups per CU (stretches of 104)
 // 7.9e6 bytes/s, 3 per CU (77) 8.5e6, 4 per CU (52) 8.4e6; the longer stretches win at few streams.
+// After the later changes to the backward pass the balance moved: stretches of 154 (two
+// load-then-add rounds per gate chain; the whole chain at once, 307, spills) with two workgroups
+// per CU give 1.14e7 bytes/s at 4096 streams and 7.9e6 at 256, stretches of 77 with three per CU
+// 1.06e7 and 6.65e6.  Both builds exist; GMX_LSTM_BUILD=3 in the environment picks the second.
+// (Tried and dropped: a dense [input][50] pitch for the gate matrices instead of [input][64] -- 22%
+// fewer bytes, but rows that no longer start on a cache line: 15-25% slower at every stream count.)
 #ifndef GMX_LSTM_STRETCH
 #define GMX_LSTM_STRETCH 77
 #define GMX_LSTM_Q 16
@@ -103,7 +110,8 @@ __device__ __forceinline__ float clipf(float a) { return a < -kClip ? -kClip : (
 
 }  // namespace
 
-__global__ void __launch_bounds__(256, GMX_LSTM_BLOCKS)
+template <int kStretch, int kBlocks>
+__global__ void __launch_bounds__(256, kBlocks)
 gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
   __shared__ Lds L;
   const GmxLstmDev& dv = *dvp;
@@ -160,7 +168,6 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
         const GmxLstmGateOff& g = dv.gate[wave];
         const float* w = B + g.weights;
         float f = w[(uint64_t)last_byte * CP + lane];
-        constexpr int kStretch = GMX_LSTM_STRETCH;
 #pragma unroll 1
         for (int j0 = 0; j0 < LIN; j0 += kStretch) {
           float wv[kStretch];
@@ -625,7 +632,16 @@ extern "C" int gmx_lstm_prof_read(unsigned long long* out) {
 extern "C" hipError_t gmx_launch_lstm_kernel(const GmxLstmDev* dv, const GmxLstmRunArgs* args, int n_streams,
                                              hipStream_t stream) {
   (void)hipGetLastError();
-  hipLaunchKernelGGL(gmx_lstm_kernel, dim3(n_streams), dim3(256), 0, stream, dv, *args);
+  int build = 2;
+  if (const char* e = getenv("GMX_LSTM_BUILD")) {  // tuning: force the 2- or 3-workgroups-per-CU build
+    if (e[0] == '2') build = 2;
+    if (e[0] == '3') build = 3;
+  }
+  if (build == 2)
+    hipLaunchKernelGGL((gmx_lstm_kernel<154, 2>), dim3(n_streams), dim3(256), 0, stream, dv, *args);
+  else
+    hipLaunchKernelGGL((gmx_lstm_kernel<GMX_LSTM_STRETCH, GMX_LSTM_BLOCKS>), dim3(n_streams), dim3(256), 0, stream,
+                       dv, *args);
   return hipGetLastError();
 }
 
