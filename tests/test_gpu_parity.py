@@ -228,3 +228,52 @@ def test_compressed_bytes_identical(gpu, oracle):
     a, b = oracle.encode(bits, P[0]), oracle.encode(bits, p_ref)
     assert a == b and len(a) < T // 8  # identical, and the learnable stream really compresses
     g.close()
+
+
+def test_double_buffered_batches_keep_their_order(gpu, oracle):
+    """Two record batches used alternately the way BASELINE configs[3] asks for: while the kernel
+    works on one, the other's records cross PCIe on the upload stream and the previous results come
+    back on the download stream.  Events, not host waits, keep upload -> run -> download of a batch
+    and run(k) -> run(k+1) of the bank in order; the floats must be the oracle's."""
+    from gmix_amd import topology
+    topo = topology.stock(90)
+    S, T, chunk = 6, 2400, 300
+    streams = [oracle.synth(90, 33, T, seed=31 + 7 * s, ctx_mode=3, ctx_mod=6, zero_mod=9, bit_mode=1) for s in range(S)]
+    g = gpu.MixerGroup(topo, S)
+    bs = [gpu.Batch(g, chunk, outputs=True, mask=True) for _ in range(2)]
+    P = np.zeros((S, T), np.float32)
+    O = np.zeros((S, T, 33), np.float32)
+
+    def fill(b, k):
+        for s, (pred, act, ctx, bits) in enumerate(streams):
+            sl = slice(k * chunk, (k + 1) * chunk)
+            b.set_records(s, pred[sl], act[sl], ctx[sl], bits[sl])
+
+    n = T // chunk
+    fill(bs[0], 0)
+    bs[0].upload(chunk)
+    for k in range(n):
+        cur, nxt = bs[k & 1], bs[(k + 1) & 1]
+        g.run(cur, chunk, learn=True)
+        if k + 1 < n:
+            nxt.wait()                        # results of chunk k-1 are on the host ...
+            if k >= 1:
+                P[:, (k - 1) * chunk:k * chunk] = nxt.p[:, :chunk]
+                O[:, (k - 1) * chunk:k * chunk] = nxt.outputs[:, :chunk]
+            fill(nxt, k + 1)                  # ... so its host arrays may be refilled
+            nxt.upload(chunk)                 # beside the kernel of chunk k
+        cur.download(chunk)
+    for k in (n - 2, n - 1):
+        b = bs[k & 1]
+        b.wait()
+        P[:, k * chunk:(k + 1) * chunk] = b.p[:, :chunk]
+        O[:, k * chunk:(k + 1) * chunk] = b.outputs[:, :chunk]
+    for s in range(S):
+        ob = oracle.Bank(90, topo.skip, topo.mixers)
+        p_ref, o_ref = ob.run(*streams[s])
+        assert np.array_equal(O[s].view(np.uint32), o_ref.view(np.uint32)), s
+        assert np.array_equal(P[s].view(np.uint32), p_ref.view(np.uint32)), s
+        assert g.export(s) == (ob.export_long(), ob.export_short())
+    for b in bs:
+        b.close()
+    g.close()
