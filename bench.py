@@ -82,6 +82,8 @@ def main():
                     help="0: fresh 32-bit gate contexts every bit (BASELINE configs[1]); 2/3: contexts held "
                          "for 8 bits like byte-boundary contexts (oracle/gmx_synth.h)")
     ap.add_argument("--ctx-mod", type=int, default=1)
+    ap.add_argument("--stock-pairs", action="store_true",
+                    help="--config stock: the lane-pair kernel (gmx_wide.hip) instead of the generated streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-bits", type=int, default=4_000_000)
     args = ap.parse_args()
@@ -121,6 +123,10 @@ def main():
         import ctypes
         g.L.gmx_debug_single_variant.argtypes = [ctypes.c_void_p, ctypes.c_int]
         assert g.L.gmx_debug_single_variant(g.h, args.variant) == 0
+    if args.stock_pairs:
+        import ctypes
+        g.L.gmx_debug_stock_pairs.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        assert g.L.gmx_debug_stock_pairs(g.h, 1) == 0
     ring = [gmix_amd.Batch(g, T, outputs=False, mask=False) for _ in range(args.ring)]
     for i, b in enumerate(ring):
         b.fill_synthetic(T, seed=0x9E3779B97F4A7C15 + 1000003 * (rank * args.ring + i), restart=True,
@@ -176,7 +182,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": ("gmx_single_kernel" if topo.n_mixers == 1 else
-                                    "gmx_stock_kernel" if args.config == "stock" else ("gmx_wide_kernel" if args.config == "synth3" else "gmx_bank_kernel")),
+                                    ("gmx_wide_kernel" if args.stock_pairs else "gmx_stock_kernel") if args.config == "stock" else ("gmx_wide_kernel" if args.config == "synth3" else "gmx_bank_kernel")),
                          "kernel_ms_avg": avg_ms,
                          "algorithmic_bytes_per_bit": bytes_per_bit,
                          "bytes_per_launch": bytes_per_launch},

@@ -45,7 +45,7 @@ hipError_t gmx_launch_stock_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* a
 hipError_t gmx_launch_single_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_inputs,
                                     int variant, hipStream_t stream);
 hipError_t gmx_launch_wide_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_streams, int has_mask,
-                                  hipStream_t stream);
+                                  int n_inputs, hipStream_t stream);
 hipError_t gmx_launch_synth_kernel(const GmxSynthArgs* args, hipStream_t stream);
 hipError_t gmx_launch_init_scal(uint8_t* banks, uint64_t bank_bytes, uint64_t scal_off, int m,
                                 int n_streams, hipStream_t stream);
@@ -106,6 +106,7 @@ struct gmx_group {
   bool mailbox_on_device = true;   // tests: false keeps the sessions' command blocks in pinned host memory
   bool force_general = false;      // tests: route everything through the general kernel
   bool stock_exact = false;        // tests: stock kernels use their masked forward chains only
+  bool stock_pairs = false;        // batched runs of the stock shape through gmx_wide_kernel<90, 64> (lane pairs)
   int single_variant = 0;          // tests/tuning: lanes per stream of the single-mixer kernel (0 = default)
 };
 
@@ -519,13 +520,14 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
                      g->topo.has_final && g->topo.mx[23].stride == 128 && !g->force_general;
   // The 256-input 24/8/1 bank (BASELINE configs[2]) likewise, two lanes per layer-0 row
   // (gmx_wide.hip); batched Predict(+Learn) only.
-  const bool wide = g->topo.n == 256 && g->topo.l0 == 24 && g->topo.l1 == 8 && g->topo.n_skip == 1 &&
-                    g->topo.has_final && g->topo.mx[23].stride == 288 && (mode & GMX_MODE_PREDICT) &&
-                    !(mode & GMX_MODE_LATCH) && !g->force_general;
+  const bool wide = ((g->topo.n == 256 && g->topo.mx[23].stride == 288) ||
+                     (g->topo.n == 90 && g->topo.mx[23].stride == 128 && g->stock_pairs && !g->stock_exact)) &&
+                    g->topo.l0 == 24 && g->topo.l1 == 8 && g->topo.n_skip == 1 && g->topo.has_final &&
+                    (mode & GMX_MODE_PREDICT) && !(mode & GMX_MODE_LATCH) && !g->force_general;
   if (single)
     HIPCHK(gmx_launch_single_kernel(g->topo_dev, &a, g->topo.n, g->single_variant, g->stream));
   else if (wide)
-    HIPCHK(gmx_launch_wide_kernel(g->topo_dev, &a, ns, a.mask != nullptr, g->stream));
+    HIPCHK(gmx_launch_wide_kernel(g->topo_dev, &a, ns, a.mask != nullptr, g->topo.n, g->stream));
   else if (stock)
     HIPCHK(gmx_launch_stock_kernel(g->topo_dev, &a, ns, (g->topo.lds_misc + 256u) * 4u,
                                    a.mask != nullptr, g->stream));
@@ -1026,6 +1028,14 @@ extern "C" int gmx_debug_single_variant(gmx_group* g, int lanes_per_stream) {
              lanes_per_stream != 64 && lanes_per_stream != 165 && lanes_per_stream != 325))
     return GMX_ERR_INVALID;
   g->single_variant = lanes_per_stream;
+  return GMX_OK;
+}
+
+// Batched runs of the stock shape: 1 = the lane-pair kernel (gmx_wide.hip), 0 = the generated
+// instruction streams (gmx_stock.hip).
+extern "C" int gmx_debug_stock_pairs(gmx_group* g, int on) {
+  if (!g) return GMX_ERR_INVALID;
+  g->stock_pairs = on != 0;
   return GMX_OK;
 }
 

@@ -36,29 +36,40 @@ typedef float gmx_f4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kN = 256, kL0 = 24, kL1 = 8, kM = kL0 + kL1 + 1;
-constexpr int kStride0 = 288;  // stored floats of a layer-0 row (weight sizes 256..279, zero padded)
-constexpr int kHalf = 144;     // floats per lane of a layer-0 row
-constexpr int kQ = kHalf / 4;  // 36 register quads per lane
+constexpr int kL0 = 24, kL1 = 8, kM = kL0 + kL1 + 1;
 constexpr int kQS = 9;         // quads of a layer-1 / final row that can hold weights (<= 33 of 64 stored floats)
-constexpr int kQB = (kN - kHalf) / 4;  // 28: quads of the upper half that face inputs; cascade weights follow
 constexpr int kFinLane = 56;
-// Staging image of the rows in LDS (floats): 48 layer-0 halves `kPitch` apart -- 144 floats + 4, so
-// that the 16 lanes of a ds_read_b128 group, each reading its own row at the same quad, hit 16
-// different bank quads -- then the 9 small rows `kPitchS` apart.
-constexpr int kPitch = kHalf + 4, kPitchS = 4 * kQS + 4;
-constexpr int kStageSmall = 2 * kL0 * kPitch;
-constexpr int kStageFloats = kStageSmall + (kL1 + 1) * kPitchS;
-// staging slot of lane h's row piece, its length in 16-byte lanes (0: lane h holds no row)
-__host__ __device__ constexpr int stage_off(int h) {
-  return h < kL0 ? h * kPitch
-         : h < 32 ? kStageSmall + (h - kL0) * kPitchS
-         : h < 32 + kL0 ? (kL0 + h - 32) * kPitch
-         : h == kFinLane ? kStageSmall + kL1 * kPitchS : 0;
-}
-__host__ __device__ constexpr int stage_lanes(int h) {
-  return (h < kL0 || (h >= 32 && h < 32 + kL0)) ? kQ : ((h < 32 || h == kFinLane) ? kQS : 0);
-}
+constexpr int kPitchS = 4 * kQS + 4;
+
+// The shape: N inputs, layer-0 rows stored as 2 * HALF floats (weight sizes N .. N+23, zero padded),
+// HALF of them per lane of a pair.  256 inputs: HALF 144; the reference's 90 inputs: HALF 64.
+template <int N, int HALF>
+struct WideShape {
+  static constexpr int kN = N, kHalf = HALF;
+  static constexpr int kNPad = (N + 3) / 4 * 4;   // floats of a prediction record
+  static constexpr int kMW = (N + 31) / 32;       // words of an active mask
+  static constexpr int kQ = HALF / 4;             // register quads per lane
+  static constexpr int kUp = N - HALF;            // inputs the upper half faces; its cascade weights follow
+  static constexpr int kQU = (kUp + 3) / 4;       // quads of the upper half that face inputs (the last one maybe partly)
+  // Staging image of the rows in LDS (floats): 48 layer-0 halves `kPitch` apart -- HALF floats + 4,
+  // so that the 16 lanes of a ds_read_b128 group, each reading its own row at the same quad, hit
+  // 16 different bank quads -- then the 9 small rows `kPitchS` apart.
+  static constexpr int kPitch = HALF + 4;
+  static constexpr int kStageSmall = 2 * kL0 * kPitch;
+  static constexpr int kStageFloats = kStageSmall + (kL1 + 1) * kPitchS;
+  static_assert(HALF % 4 == 0 && HALF <= N && N - HALF + kL0 - 1 <= HALF, "layer-0 rows must split into two lanes");
+  static_assert((kPitch / 4) % 2 == 1, "odd quad pitch keeps the transposed reads conflict-free");
+  // staging slot of lane h's row piece, its length in 16-byte lanes (0: lane h holds no row)
+  static constexpr int stage_off(int h) {
+    return h < kL0 ? h * kPitch
+           : h < 32 ? kStageSmall + (h - kL0) * kPitchS
+           : h < 32 + kL0 ? (kL0 + h - 32) * kPitch
+           : h == kFinLane ? kStageSmall + kL1 * kPitchS : 0;
+  }
+  static constexpr int stage_lanes(int h) {
+    return (h < kL0 || (h >= 32 && h < 32 + kL0)) ? kQ : ((h < 32 || h == kFinLane) ? kQS : 0);
+  }
+};
 
 __device__ __forceinline__ void wide_ld16(gmx_f4& d, const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
@@ -105,11 +116,14 @@ __device__ __forceinline__ float el(const gmx_f4& v, int e) { return e == 0 ? v.
 
 }  // namespace
 
-template <bool HAS_MASK>
+template <int N, int HALF, bool HAS_MASK>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
-  __shared__ __attribute__((aligned(16))) float xin[kN];
-  __shared__ __attribute__((aligned(16))) float stage[kStageFloats];
+  using SH = WideShape<N, HALF>;
+  constexpr int kN = SH::kN, kHalf = SH::kHalf, kNPad = SH::kNPad, kMW = SH::kMW, kQ = SH::kQ, kUp = SH::kUp,
+                kQU = SH::kQU, kPitch = SH::kPitch, kStageSmall = SH::kStageSmall;
+  __shared__ __attribute__((aligned(16))) float xin[kNPad + 4];
+  __shared__ __attribute__((aligned(16))) float stage[SH::kStageFloats];
   __shared__ uint64_t s_tab[32];
   const int lane = threadIdx.x;
   const int rec = a.rec_base + (int)blockIdx.x;
@@ -144,8 +158,8 @@ gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
   const uint32_t row_bytes = d.stride * 4u;
 
   const uint64_t RS = a.rec_stride;
-  const float* const pred_s = a.pred + (uint64_t)rec * RS * kN;
-  const uint32_t* const mask_s = HAS_MASK ? a.mask + (uint64_t)rec * RS * (kN / 32) : nullptr;
+  const float* const pred_s = a.pred + (uint64_t)rec * RS * kNPad;
+  const uint32_t* const mask_s = HAS_MASK ? a.mask + (uint64_t)rec * RS * kMW : nullptr;
   const uint32_t* const ctx_s = a.ctx + (uint64_t)rec * RS * kM;
   const uint8_t* const bits_s = a.bits + (uint64_t)rec * RS;
   const float* const dec_s = a.decay + (uint64_t)a.decay_idx[blockIdx.x] * T;
@@ -163,7 +177,7 @@ gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
   // Rows travel between HBM and the registers through the staging image, so that every global
   // access is a coalesced run of 16-byte lanes (lane-private 16-byte accesses cost the texture
   // path four tag look-ups per 64-byte line, and four partial writes: measured, it was 70% busy).
-  float* const my_stage = stage + stage_off(0) + (is_l0 ? (half * kL0 + li) * kPitch
+  float* const my_stage = stage + (is_l0 ? (half * kL0 + li) * kPitch
                                                         : kStageSmall + (is_fin ? kL1 : (li - kL0)) * kPitchS);
   const uint32_t stage_base = wide_lds_addr(stage);
   const uint32_t lane16 = (uint32_t)lane * 16u;
@@ -183,10 +197,10 @@ gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
     }
 #pragma unroll
     for (int h = 0; h <= kFinLane; ++h) {
-      if (stage_lanes(h) == 0) continue;
-      const uint64_t m = ((em >> h) & 1u) ? ((1ull << stage_lanes(h)) - 1ull) : 0ull;
+      if (SH::stage_lanes(h) == 0) continue;
+      const uint64_t m = ((em >> h) & 1u) ? ((1ull << SH::stage_lanes(h)) - 1ull) : 0ull;
       const uint64_t sb = ((uint64_t)readlane_u(dhi, h) << 32) | readlane_u(dlo, h);
-      const gmx_f4 v = *(const gmx_f4*)(stage + stage_off(h) + 4 * (lane < stage_lanes(h) ? lane : 0));
+      const gmx_f4 v = *(const gmx_f4*)(stage + SH::stage_off(h) + 4 * (lane < SH::stage_lanes(h) ? lane : 0));
       wide_st16(sb, lane16, v, m);
     }
   };
@@ -195,10 +209,10 @@ gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
     const uint32_t slo = (uint32_t)src, shi = (uint32_t)(src >> 32);
 #pragma unroll
     for (int h = 0; h <= kFinLane; ++h) {
-      if (stage_lanes(h) == 0) continue;
-      const uint64_t m = ((nm >> h) & 1u) ? ((1ull << stage_lanes(h)) - 1ull) : 0ull;
+      if (SH::stage_lanes(h) == 0) continue;
+      const uint64_t m = ((nm >> h) & 1u) ? ((1ull << SH::stage_lanes(h)) - 1ull) : 0ull;
       const uint64_t sb = ((uint64_t)readlane_u(shi, h) << 32) | readlane_u(slo, h);
-      wide_dma16(sb, lane16, stage_base + (uint32_t)stage_off(h) * 4u, m);
+      wide_dma16(sb, lane16, stage_base + (uint32_t)SH::stage_off(h) * 4u, m);
     }
   };
 
@@ -208,8 +222,8 @@ gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
   auto request = [&](uint64_t t) {
     const uint64_t tt = t < T ? t : T - 1;  // past the end: a harmless re-read of the last record
     wide_ld4(ctx_n, ctx_s + tt * (uint64_t)kM + mxi);
-    wide_ld16(x_n, pred_s + tt * (uint64_t)kN + 4 * lane);
-    if (HAS_MASK) wide_ld4(mask_n, mask_s + tt * (uint64_t)(kN / 32) + (lane & 7));
+    wide_ld16(x_n, pred_s + tt * (uint64_t)kNPad + 4 * (4 * lane < kNPad ? lane : 0));
+    if (HAS_MASK) wide_ld4(mask_n, mask_s + tt * (uint64_t)kMW + (lane < kMW ? lane : 0));
     wide_ld1(bit_n, bits_s + tt);
     wide_ld4(dec_n, dec_s + tt);
   };
@@ -251,18 +265,19 @@ gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
     request(t + 1);  // a whole bit ahead of its use
 
     // ---- the blackboard of this bit into LDS ----------------------------------------------
-    *(gmx_f4*)(xin + 4 * lane) = xv;
+    const bool has_x = 4 * lane < kNPad;
+    if (has_x) *(gmx_f4*)(xin + 4 * lane) = xv;
     const float skip = xin[skip_idx];  // raw, possibly stale (mixer.cpp:76-79)
     if (HAS_MASK) {
       // only active_models are visited (mixer.cpp:57-59): silent slots contribute nothing
-      const uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute((lane >> 3) << 2, (int)mword);
+      const uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute((has_x ? (lane >> 3) : 0) << 2, (int)mword);
       const uint32_t b = word >> ((4u * (uint32_t)lane) & 31u);
       gmx_f4 v = xv;
       v.x = (b & 1u) ? v.x : 0.f;
       v.y = (b & 2u) ? v.y : 0.f;
       v.z = (b & 4u) ? v.z : 0.f;
       v.w = (b & 8u) ? v.w : 0.f;
-      *(gmx_f4*)(xin + 4 * lane) = v;
+      if (has_x) *(gmx_f4*)(xin + 4 * lane) = v;
     }
     const bool seen = act && rs != 0;  // an unseen row is "no row": output 0 (mixer.cpp:52-55)
 
@@ -279,12 +294,12 @@ gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
     // ---- ... handed to lanes 32..55, which go on with inputs 144..255 ---------------------
     acc = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 31)) << 2, __float_as_int(acc)));
 #pragma unroll
-    for (int q = 0; q < kQB; ++q) {
+    for (int q = 0; q < kQU; ++q) {
       const gmx_f4 x = *(const gmx_f4*)(xin + kHalf + 4 * q);
-      acc = acc + x.x * w[q].x;
-      acc = acc + x.y * w[q].y;
-      acc = acc + x.z * w[q].z;
-      acc = acc + x.w * w[q].w;
+      if (4 * q + 0 < kUp) acc = acc + x.x * w[q].x;
+      if (4 * q + 1 < kUp) acc = acc + x.y * w[q].y;
+      if (4 * q + 2 < kUp) acc = acc + x.z * w[q].z;
+      if (4 * q + 3 < kUp) acc = acc + x.w * w[q].w;
     }
     acc = seen ? acc : 0.f;
     // ---- layer-0 cascade: mixer k adds outputs 0..k-1 in order (mixer.cpp:60-64) -----------
@@ -294,7 +309,7 @@ gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
     for (int i = 0; i < kL0; ++i) {
       o0[i] = readlane_f(acc, 32 + i);
       if (i + 1 < kL0) {
-        const float wt = el(w[kQB + i / 4], i % 4);
+        const float wt = el(w[(kUp + i) / 4], (kUp + i) % 4);
         acc = (up0 && li > i) ? acc + o0[i] * wt : acc;
       }
     }
@@ -343,25 +358,26 @@ gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
       // w -= update * x over the segments Predict walked (mixer.cpp:129-172).  Lower halves and
       // small rows: quads 0..35 of [x | nothing]; upper halves: inputs 144..255, then the
       // cascade inputs (outputs of the layer-0 mixers before this one), then padding.
-      const float* const xu = xin + (half && is_l0 ? kHalf : 0);
 #pragma unroll
       for (int q = 0; q < kQ; ++q) {
-        gmx_f4 x = gmx_f4{0.f, 0.f, 0.f, 0.f};
-        if (q < kQB) {
-          x = *(const gmx_f4*)(xu + 4 * q);
-        } else {
-          const gmx_f4 xl = *(const gmx_f4*)(xin + 4 * q);  // lower halves: inputs 112..143
-          float c[4];
+        // lower halves: inputs 4q .. 4q+3 (all < HALF <= N); upper halves: local index j faces
+        // input HALF + j for j < kUp, then the cascade input j - kUp (an output of a layer-0
+        // mixer before this one), then padding
+        const gmx_f4 xl = *(const gmx_f4*)(xin + 4 * q);
+        gmx_f4 xh = gmx_f4{0.f, 0.f, 0.f, 0.f};
+        if (4 * q < kUp) xh = *(const gmx_f4*)(xin + kHalf + 4 * q);
+        float c[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int i = 4 * (q - kQB) + e;  // cascade input index of an upper half
-            c[e] = (i + 1 < kL0 && li > i) ? o0[i < kL0 ? i : 0] : 0.f;
-          }
-          x.x = half ? c[0] : xl.x;
-          x.y = half ? c[1] : xl.y;
-          x.z = half ? c[2] : xl.z;
-          x.w = half ? c[3] : xl.w;
+        for (int e = 0; e < 4; ++e) {
+          const int j = 4 * q + e;
+          const int i = j - kUp;  // cascade input index of an upper half
+          c[e] = j < kUp ? el(xh, e) : ((i + 1 < kL0 && li > i) ? o0[(i >= 0 && i < kL0) ? i : 0] : 0.f);
         }
+        gmx_f4 x;
+        x.x = half ? c[0] : xl.x;
+        x.y = half ? c[1] : xl.y;
+        x.z = half ? c[2] : xl.z;
+        x.w = half ? c[3] : xl.w;
         if (q < kQS) {
           // layer-1 / final rows: layer-0 outputs, own-layer outputs before this mixer (all of
           // them for the final mixer), the skip input, padding
@@ -406,14 +422,24 @@ gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
   }
 }
 
-// Eligible: n_inputs 256, 24 layer-0 + 8 layer-1 + final, one skip input, batched Predict(+Learn)
-// (the host checks that before calling).
+// Eligible: 256 inputs (shape 0) or the reference's 90 inputs (shape 1), 24 layer-0 + 8 layer-1 +
+// final, one skip input, batched Predict(+Learn) (the host checks that before calling).
 extern "C" hipError_t gmx_launch_wide_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_streams,
-                                             int has_mask, hipStream_t stream) {
+                                             int has_mask, int n_inputs, hipStream_t stream) {
   (void)hipGetLastError();
-  if (has_mask)
-    hipLaunchKernelGGL(gmx_wide_kernel<true>, dim3(n_streams), dim3(64), 0, stream, tp_dev, *args);
-  else
-    hipLaunchKernelGGL(gmx_wide_kernel<false>, dim3(n_streams), dim3(64), 0, stream, tp_dev, *args);
+  const dim3 grid(n_streams), block(64);
+  if (n_inputs == 256) {
+    if (has_mask)
+      hipLaunchKernelGGL((gmx_wide_kernel<256, 144, true>), grid, block, 0, stream, tp_dev, *args);
+    else
+      hipLaunchKernelGGL((gmx_wide_kernel<256, 144, false>), grid, block, 0, stream, tp_dev, *args);
+  } else if (n_inputs == 90) {
+    if (has_mask)
+      hipLaunchKernelGGL((gmx_wide_kernel<90, 64, true>), grid, block, 0, stream, tp_dev, *args);
+    else
+      hipLaunchKernelGGL((gmx_wide_kernel<90, 64, false>), grid, block, 0, stream, tp_dev, *args);
+  } else {
+    return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }

@@ -15,9 +15,11 @@ def beq(a, b):
                           np.ascontiguousarray(b, np.float32).view(np.uint32))
 
 
-def run(gpu, topo, streams, chunk, force_general, mask=True, learn=True, exact=False):
+def run(gpu, topo, streams, chunk, force_general, mask=True, learn=True, exact=False, pairs=False):
     S, T = len(streams), len(streams[0][3])
     g = gpu.MixerGroup(topo, S)
+    g.L.gmx_debug_stock_pairs.argtypes = [C.c_void_p, C.c_int]
+    assert g.L.gmx_debug_stock_pairs(g.h, 1 if pairs else 0) == 0
     g.L.gmx_debug_force_general.argtypes = [C.c_void_p, C.c_int]
     g.L.gmx_debug_force_general(g.h, 1 if force_general else 0)
     g.L.gmx_debug_stock_exact.argtypes = [C.c_void_p, C.c_int]
@@ -61,9 +63,15 @@ def test_stock_kernel_equals_general_kernel_and_oracle(gpu, oracle, kw, mask):
     assert beq(P1, P3) and beq(O1, O3)
     for s in range(S):
         assert g1.export(s) == g3.export(s)
+    # the lane-pair kernel (gmx_wide.hip instantiated for 90 inputs) gives the same floats
+    g4, P4, O4 = run(gpu, topo, streams, 700, force_general=False, mask=mask, pairs=True)
+    assert beq(P1, P4) and beq(O1, O4)
+    for s in range(S):
+        assert g1.export(s) == g4.export(s)
     g1.close()
     g2.close()
     g3.close()
+    g4.close()
 
 
 def test_stock_kernel_non_finite_values_stay_where_the_reference_puts_them(gpu, oracle):
