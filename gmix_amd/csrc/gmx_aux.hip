@@ -226,3 +226,42 @@ extern "C" hipError_t gmx_launch_init_scal(uint8_t* banks, uint64_t bank_bytes, 
                      bank_bytes, scal_off, m, n_streams);
   return hipGetLastError();
 }
+
+// ---- the bit-count factor of the learning-rate decay, for many different bit counts ---------
+// float(0.9 / pow(1e-7 * steps_ + 0.8, 0.8)) (mixer.cpp:111) is a function of the bit count only;
+// streams that stand at the same count share one table row, which the host fills with the libm the
+// reference calls.  When a launch covers streams at MANY different counts that loop would dwarf
+// the kernel, so the table is made here -- and stays the reference's, bit for bit, without
+// restating glibc's pow: the value needed is a FLOAT.  This device's pow and glibc's both lie
+// within a few ulp (of double) of the true value; if every double within 64 ulp of ours rounds to
+// the same float, that float is glibc's too.  The rare entry where it does not (a double within
+// 2^-46 of a float rounding boundary: about one in 2^22) is reported and the host computes it.
+struct GmxDecayArgs {
+  const uint64_t* steps0;  // [U] bit count of row u at t = 0
+  float* table;            // [U][T]
+  uint32_t* amb;           // [0]: count of unsettled entries, [1 .. cap]: their flat indices
+  uint32_t amb_cap, U;
+  uint64_t T;
+};
+
+__global__ void __launch_bounds__(256) gmx_decay_kernel(const GmxDecayArgs a) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= (uint64_t)a.U * a.T) return;
+  const uint64_t steps = a.steps0[i / a.T] + i % a.T;
+  const double x = 0.0000001 * (double)steps + 0.8;
+  const double d = 0.9 / pow(x, 0.8);
+  const double margin = d * 0x1p-46;
+  const float f = (float)d, lo = (float)(d - margin), hi = (float)(d + margin);
+  a.table[i] = f;
+  if (lo != hi) {
+    const uint32_t k = atomicAdd(&a.amb[0], 1u);
+    if (k < a.amb_cap) a.amb[1 + k] = (uint32_t)i;
+  }
+}
+
+extern "C" hipError_t gmx_launch_decay_kernel(const GmxDecayArgs* args, hipStream_t stream) {
+  (void)hipGetLastError();
+  const uint64_t n = (uint64_t)args->U * args->T;
+  hipLaunchKernelGGL(gmx_decay_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *args);
+  return hipGetLastError();
+}

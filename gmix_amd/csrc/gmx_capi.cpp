@@ -47,6 +47,14 @@ hipError_t gmx_launch_single_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* 
 hipError_t gmx_launch_wide_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_streams, int has_mask,
                                   int n_inputs, hipStream_t stream);
 hipError_t gmx_launch_synth_kernel(const GmxSynthArgs* args, hipStream_t stream);
+struct GmxDecayArgs {
+  const uint64_t* steps0;
+  float* table;
+  uint32_t* amb;
+  uint32_t amb_cap, U;
+  uint64_t T;
+};
+hipError_t gmx_launch_decay_kernel(const GmxDecayArgs* args, hipStream_t stream);
 hipError_t gmx_launch_init_scal(uint8_t* banks, uint64_t bank_bytes, uint64_t scal_off, int m,
                                 int n_streams, hipStream_t stream);
 hipError_t gmx_launch_math_probe(const float* x, float* y, uint64_t n, int what, hipStream_t stream);
@@ -92,6 +100,13 @@ struct gmx_group {
     hipEvent_t done = nullptr;     // recorded behind the kernel that read this slot
     hipEvent_t ready = nullptr;    // recorded behind the upload on copy_stream
     bool busy = false;
+    // tables made on the device (many different bit counts in one launch)
+    uint64_t* st_dev = nullptr;    // [st_cap] bit counts of the table rows
+    uint64_t* st_host = nullptr;   // pinned
+    uint32_t* amb_dev = nullptr;   // [1 + kDecayAmbCap] unsettled entries
+    uint32_t* amb_host = nullptr;  // pinned
+    float* patch_host = nullptr;   // pinned [kDecayAmbCap]
+    size_t st_cap = 0;
   } decay[2];
   hipStream_t copy_stream = nullptr;  // uploads of the decay tables, beside the running kernel
   // record batches travel on streams of their own, beside the running kernel (BASELINE configs[3]:
@@ -106,6 +121,7 @@ struct gmx_group {
   bool mailbox_on_device = true;   // tests: false keeps the sessions' command blocks in pinned host memory
   bool force_general = false;      // tests: route everything through the general kernel
   bool stock_exact = false;        // tests: stock kernels use their masked forward chains only
+  bool decay_on_host = false;      // tests: the decay tables always from the host's libm loop
   bool stock_pairs = false;        // batched runs of the stock shape through gmx_wide_kernel<90, 64> (lane pairs)
   int single_variant = 0;          // tests/tuning: lanes per stream of the single-mixer kernel (0 = default)
 };
@@ -347,6 +363,11 @@ extern "C" void gmx_group_destroy(gmx_group* g) {
   if (g->latch_out) (void)hipFree(g->latch_out);
   if (g->topo_dev) (void)hipFree(g->topo_dev);
   for (auto& d : g->decay) {
+    if (d.st_dev) (void)hipFree(d.st_dev);
+    if (d.st_host) (void)hipHostFree(d.st_host);
+    if (d.amb_dev) (void)hipFree(d.amb_dev);
+    if (d.amb_host) (void)hipHostFree(d.amb_host);
+    if (d.patch_host) (void)hipHostFree(d.patch_host);
     if (d.dev) (void)hipFree(d.dev);
     if (d.idx_dev) (void)hipFree(d.idx_dev);
     if (d.host) (void)hipHostFree(d.host);
@@ -429,6 +450,55 @@ static float decay_base(uint64_t steps) { return (float)(0.9 / pow(0.0000001 * s
 
 #include "gmx_session.inc"
 
+static const uint32_t kDecayAmbCap = 4096;
+static const size_t kDecayDeviceMin = 8192;  // table entries from which the device makes the table
+
+// The decay table of `uniq` rows x T made on the device (gmx_decay_kernel), the entries it could
+// not settle computed here with libm.  Returns GMX_ERR_STATE if there were too many of those
+// (the caller then fills the table on the host).
+static int decay_table_on_device(gmx_group* g, gmx_group::DecaySlot& d, const std::map<uint64_t, uint32_t>& uniq,
+                                 uint64_t T) {
+  const size_t U = uniq.size();
+  if (U > d.st_cap) {
+    if (d.st_dev) (void)hipFree(d.st_dev);
+    if (d.st_host) (void)hipHostFree(d.st_host);
+    d.st_dev = nullptr;
+    d.st_host = nullptr;
+    d.st_cap = 0;
+    const size_t cap = U + U / 2 + 64;
+    HIPCHK(hipMalloc((void**)&d.st_dev, cap * sizeof(uint64_t)));
+    HIPCHK(hipHostMalloc((void**)&d.st_host, cap * sizeof(uint64_t), hipHostMallocDefault));
+    d.st_cap = cap;
+  }
+  if (!d.amb_dev) {
+    HIPCHK(hipMalloc((void**)&d.amb_dev, (1 + kDecayAmbCap) * sizeof(uint32_t)));
+    HIPCHK(hipHostMalloc((void**)&d.amb_host, (1 + kDecayAmbCap) * sizeof(uint32_t), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&d.patch_host, kDecayAmbCap * sizeof(float), hipHostMallocDefault));
+  }
+  for (auto& kv : uniq) d.st_host[kv.second] = kv.first;
+  hipStream_t cs = g->copy_stream;
+  HIPCHK(hipMemcpyAsync(d.st_dev, d.st_host, U * sizeof(uint64_t), hipMemcpyHostToDevice, cs));
+  HIPCHK(hipMemsetAsync(d.amb_dev, 0, sizeof(uint32_t), cs));
+  GmxDecayArgs a;
+  a.steps0 = d.st_dev;
+  a.table = d.dev;
+  a.amb = d.amb_dev;
+  a.amb_cap = kDecayAmbCap;
+  a.U = (uint32_t)U;
+  a.T = T;
+  HIPCHK(gmx_launch_decay_kernel(&a, cs));
+  HIPCHK(hipMemcpyAsync(d.amb_host, d.amb_dev, (1 + kDecayAmbCap) * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+  HIPCHK(hipStreamSynchronize(cs));
+  const uint32_t n = d.amb_host[0];
+  if (n > kDecayAmbCap) return GMX_ERR_STATE;
+  for (uint32_t k = 0; k < n; ++k) {
+    const uint32_t i = d.amb_host[1 + k];
+    d.patch_host[k] = decay_base(d.st_host[i / T] + i % T);
+    HIPCHK(hipMemcpyAsync(d.dev + i, d.patch_host + k, sizeof(float), hipMemcpyHostToDevice, cs));
+  }
+  return GMX_OK;
+}
+
 // Fill the group's decay tables for a run of T learning bits over streams [s0, s0+ns).
 static int prepare_decay(gmx_group* g, int s0, int ns, uint64_t T, int learn, gmx_group::DecaySlot** out) {
   std::map<uint64_t, uint32_t> uniq;
@@ -469,15 +539,25 @@ static int prepare_decay(gmx_group* g, int s0, int ns, uint64_t T, int learn, gm
     HIPCHK(hipEventCreateWithFlags(&d.ready, hipEventDisableTiming));
   }
   if (!g->copy_stream) HIPCHK(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
-  for (auto& kv : uniq) {
-    float* tab = d.host + (size_t)kv.second * T;
-    if (learn)
-      for (uint64_t t = 0; t < T; ++t) tab[t] = decay_base(kv.first + t);
-    else
-      for (uint64_t t = 0; t < T; ++t) tab[t] = 0.f;
+  // Streams at the same bit count share a row; with many different counts the device makes the
+  // table (see gmx_decay_kernel), else the host's libm loop is shorter than the detour.
+  bool on_device = false;
+  if (learn && uniq.size() > 1 && uniq.size() * T >= kDecayDeviceMin && !g->decay_on_host) {
+    const int rcd = decay_table_on_device(g, d, uniq, T);
+    if (rcd != GMX_OK && rcd != GMX_ERR_STATE) return rcd;
+    on_device = rcd == GMX_OK;
+  }
+  if (!on_device) {
+    for (auto& kv : uniq) {
+      float* tab = d.host + (size_t)kv.second * T;
+      if (learn)
+        for (uint64_t t = 0; t < T; ++t) tab[t] = decay_base(kv.first + t);
+      else
+        for (uint64_t t = 0; t < T; ++t) tab[t] = 0.f;
+    }
+    HIPCHK(hipMemcpyAsync(d.dev, d.host, uniq.size() * T * sizeof(float), hipMemcpyHostToDevice, g->copy_stream));
   }
   memcpy(d.idx_host, idx.data(), ns * sizeof(uint32_t));
-  HIPCHK(hipMemcpyAsync(d.dev, d.host, uniq.size() * T * sizeof(float), hipMemcpyHostToDevice, g->copy_stream));
   HIPCHK(hipMemcpyAsync(d.idx_dev, d.idx_host, ns * sizeof(uint32_t), hipMemcpyHostToDevice, g->copy_stream));
   HIPCHK(hipEventRecord(d.ready, g->copy_stream));
   HIPCHK(hipStreamWaitEvent(g->stream, d.ready, 0));
@@ -1037,6 +1117,49 @@ extern "C" int gmx_debug_stock_pairs(gmx_group* g, int on) {
   if (!g) return GMX_ERR_INVALID;
   g->stock_pairs = on != 0;
   return GMX_OK;
+}
+
+// Decay tables always from the host's libm loop (on != 0), or from the device when a launch covers
+// many different bit counts (the default).
+extern "C" int gmx_debug_decay_on_host(gmx_group* g, int on) {
+  if (!g) return GMX_ERR_INVALID;
+  g->decay_on_host = on != 0;
+  return GMX_OK;
+}
+
+// The device-made decay table for rows starting at steps0[0..U), T entries each, as the kernels
+// would see it (unsettled entries already replaced by libm's); *n_unsettled = how many those were.
+extern "C" int gmx_debug_decay_table(gmx_group* g, const uint64_t* steps0, int U, uint64_t T, float* out,
+                                     uint32_t* n_unsettled) {
+  if (!g || !steps0 || U < 1 || T < 1 || !out) return GMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(g->device));
+  if (!g->copy_stream) HIPCHK(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
+  gmx_group::DecaySlot tmp;
+  std::map<uint64_t, uint32_t> uniq;
+  std::vector<uint32_t> row(U);
+  for (int u = 0; u < U; ++u) {
+    auto it = uniq.find(steps0[u]);
+    if (it == uniq.end()) it = uniq.emplace(steps0[u], (uint32_t)uniq.size()).first;
+    row[u] = it->second;
+  }
+  HIPCHK(hipMalloc((void**)&tmp.dev, uniq.size() * T * sizeof(float)));
+  int rc = decay_table_on_device(g, tmp, uniq, T);
+  if (rc == GMX_OK) {
+    if (n_unsettled) *n_unsettled = tmp.amb_host[0];
+    std::vector<float> h(uniq.size() * T);
+    hipError_t e = hipMemcpyAsync(h.data(), tmp.dev, h.size() * sizeof(float), hipMemcpyDeviceToHost, g->copy_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->copy_stream);
+    if (e != hipSuccess) rc = hip_fail(e, "gmx_debug_decay_table copy");
+    else
+      for (int u = 0; u < U; ++u) memcpy(out + (size_t)u * T, h.data() + (size_t)row[u] * T, T * sizeof(float));
+  }
+  void* dv[] = {tmp.dev, tmp.st_dev, tmp.amb_dev};
+  for (void* p : dv)
+    if (p) (void)hipFree(p);
+  void* hv[] = {tmp.st_host, tmp.amb_host, tmp.patch_host};
+  for (void* p : hv)
+    if (p) (void)hipHostFree(p);
+  return rc;
 }
 
 extern "C" int gmx_debug_force_general(gmx_group* g, int on) {
