@@ -250,3 +250,42 @@ def device_count():
     n = C.c_int(0)
     check(_lib.lib().gmx_device_count(C.byref(n)), "gmx_device_count")
     return n.value
+
+
+class Lockstep:
+    """All streams of a group one bit at a time, each half step one hipGraph (gmx_lockstep)."""
+
+    def __init__(self, group, outputs=False):
+        self.g = group
+        self.L = group.L
+        h = C.c_void_p()
+        check(self.L.gmx_lockstep_create(C.byref(h), group.h, BATCH_OUTPUTS if outputs else 0), "gmx_lockstep_create")
+        self.h = h
+        # the record batch is owned by the lock-step object: a Batch view that never destroys it
+        b = Batch.__new__(Batch)
+        b.g, b.L, b.max_bits = group, group.L, 1
+        b.flags = BATCH_MASK | (BATCH_OUTPUTS if outputs else 0)
+        b.h = C.c_void_p(self.L.gmx_lockstep_batch(h))
+        b.n_pad = self.L.gmx_batch_n_pad(b.h)
+        b.mask_words = self.L.gmx_batch_mask_words(b.h)
+        b.close = lambda: None
+        self.batch = b
+
+    def predict(self):
+        check(self.L.gmx_lockstep_predict(self.h), "gmx_lockstep_predict")
+        return self.batch.p[:, 0]
+
+    def learn(self):
+        check(self.L.gmx_lockstep_learn(self.h), "gmx_lockstep_learn")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.batch.h = None
+            self.L.gmx_lockstep_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -117,6 +117,7 @@ struct gmx_group {
   gmx_batch* one = nullptr;        // 1-bit batch (one record per stream) of the per-bit surface
   std::vector<gmx_batch*> batches; // live batches; orphaned (b->g = nullptr) when the group dies
   std::vector<struct GmxSession*> sessions;  // per stream, lazily: persistent per-bit kernels
+  std::vector<struct gmx_lockstep*> locksteps;  // live lock-step objects; orphaned (ls->g = nullptr) when the group dies
   bool use_sessions = true;        // tests: per-bit calls as two launches instead of a session
   bool mailbox_on_device = true;   // tests: false keeps the sessions' command blocks in pinned host memory
   bool force_general = false;      // tests: route everything through the general kernel
@@ -155,6 +156,18 @@ struct gmx_batch {
   hipEvent_t ev_dev = nullptr;   // behind the newest device-side use (on the group's stream)
   hipEvent_t ev_down = nullptr;  // behind the newest download (on the group's download stream)
   bool up_rec = false, dev_rec = false, down_rec = false;
+};
+
+// lock-step stepping of all streams, one hipGraph per half step (gmx_lockstep.inc)
+struct gmx_lockstep {
+  gmx_group* g = nullptr;
+  gmx_batch* b = nullptr;        // one record per stream; owned
+  float* dec_host = nullptr;     // pinned [S]: float(0.9 / pow(1e-7 * steps_ + 0.8, 0.8)) of every stream's next learn
+  float* dec_dev = nullptr;      // [S]
+  uint32_t* idx_dev = nullptr;   // [S] identity: stream s uses table row s
+  hipGraph_t g_predict = nullptr, g_learn = nullptr;
+  hipGraphExec_t x_predict = nullptr, x_learn = nullptr;
+  bool predicted = false;
 };
 
 // per-bit sessions (gmx_session.inc)
@@ -357,6 +370,8 @@ extern "C" void gmx_group_destroy(gmx_group* g) {
   }
   // Batches outlive their group only as empty shells: they keep their buffers until
   // gmx_batch_destroy, but every call on them fails with GMX_ERR_INVALID from now on.
+  for (gmx_lockstep* ls : g->locksteps) ls->g = nullptr;  // their calls fail from now on; gmx_lockstep_destroy frees them
+  g->locksteps.clear();
   for (gmx_batch* b : g->batches) b->g = nullptr;
   g->batches.clear();
   if (g->banks) (void)hipFree(g->banks);
@@ -747,6 +762,8 @@ static hipError_t copy_rows(void* dst, const void* src, size_t elem_bytes, size_
   return hipMemcpy2DAsync(dst, pitch, src, pitch, width, (size_t)b->S, kind, st);
 }
 
+static const size_t kBatchOwnStreamMin = 256u * 1024u;  // bytes from which a transfer takes a stream of its own
+
 // Device-side work on the group's stream has just been queued that reads or writes b's arrays.
 static int batch_note_device_use(gmx_batch* b) {
   HIPCHK(hipEventRecord(b->ev_dev, b->g->stream));
@@ -765,9 +782,14 @@ extern "C" int gmx_batch_upload(gmx_batch* b, uint64_t n_bits) {
   HIPCHK(hipSetDevice(g->device));
   if (!gmx_batch_predictions(b) || !gmx_batch_contexts(b) || !gmx_batch_bits(b)) return GMX_ERR_NOMEM;
   if ((b->flags & GMX_BATCH_MASK) && !gmx_batch_active_mask(b)) return GMX_ERR_NOMEM;
-  if (!g->up_stream) HIPCHK(hipStreamCreateWithFlags(&g->up_stream, hipStreamNonBlocking));
-  hipStream_t st = g->up_stream;
-  if (b->dev_rec) HIPCHK(hipStreamWaitEvent(st, b->ev_dev, 0));
+  // small transfers stay on the group's stream: the cross-stream hand-shakes would cost more than
+  // the copies could ever overlap
+  const size_t bytes = (size_t)b->S * n_bits * ((size_t)t.n_pad * 4 + (size_t)t.m * 4 + 1 +
+                                                ((b->flags & GMX_BATCH_MASK) ? (size_t)t.mask_words * 4 : 0));
+  const bool own = bytes >= kBatchOwnStreamMin;
+  if (own && !g->up_stream) HIPCHK(hipStreamCreateWithFlags(&g->up_stream, hipStreamNonBlocking));
+  hipStream_t st = own ? g->up_stream : g->stream;
+  if (own && b->dev_rec) HIPCHK(hipStreamWaitEvent(st, b->ev_dev, 0));
   HIPCHK(copy_rows(b->d_pred, b->h_pred, 4, t.n_pad, b, n_bits, hipMemcpyHostToDevice, st));
   if (b->flags & GMX_BATCH_MASK)
     HIPCHK(copy_rows(b->d_mask, b->h_mask, 4, t.mask_words, b, n_bits, hipMemcpyHostToDevice, st));
@@ -775,7 +797,7 @@ extern "C" int gmx_batch_upload(gmx_batch* b, uint64_t n_bits) {
   HIPCHK(copy_rows(b->d_bits, b->h_bits, 1, 1, b, n_bits, hipMemcpyHostToDevice, st));
   HIPCHK(hipEventRecord(b->ev_up, st));
   b->up_rec = true;
-  HIPCHK(hipStreamWaitEvent(g->stream, b->ev_up, 0));
+  if (own) HIPCHK(hipStreamWaitEvent(g->stream, b->ev_up, 0));
   return GMX_OK;
 }
 
@@ -788,11 +810,15 @@ extern "C" int gmx_batch_download(gmx_batch* b, uint64_t n_bits) {
   HIPCHK(hipSetDevice(g->device));
   if (!gmx_batch_p(b)) return GMX_ERR_NOMEM;
   if ((b->flags & GMX_BATCH_OUTPUTS) && !gmx_batch_outputs(b)) return GMX_ERR_NOMEM;
-  if (!g->down_stream) HIPCHK(hipStreamCreateWithFlags(&g->down_stream, hipStreamNonBlocking));
-  hipStream_t st = g->down_stream;
-  int rc = batch_note_device_use(b);
-  if (rc) return rc;
-  HIPCHK(hipStreamWaitEvent(st, b->ev_dev, 0));
+  const size_t bytes = (size_t)b->S * n_bits * (4 + ((b->flags & GMX_BATCH_OUTPUTS) ? (size_t)t.m * 4 : 0));
+  const bool own = bytes >= kBatchOwnStreamMin;
+  if (own && !g->down_stream) HIPCHK(hipStreamCreateWithFlags(&g->down_stream, hipStreamNonBlocking));
+  hipStream_t st = own ? g->down_stream : g->stream;
+  if (own) {
+    int rc = batch_note_device_use(b);
+    if (rc) return rc;
+    HIPCHK(hipStreamWaitEvent(st, b->ev_dev, 0));
+  }
   HIPCHK(copy_rows(b->h_p, b->d_p, 4, 1, b, n_bits, hipMemcpyDeviceToHost, st));
   if (b->flags & GMX_BATCH_OUTPUTS)
     HIPCHK(copy_rows(b->h_out, b->d_out, 4, t.m, b, n_bits, hipMemcpyDeviceToHost, st));
@@ -949,6 +975,8 @@ extern "C" int gmx_bank_learn(gmx_group* g, int stream, int bit) {
   g->fwd_done[stream] = 0;
   return GMX_OK;
 }
+
+#include "gmx_lockstep.inc"
 
 // ---- persistence -------------------------------------------------------------------------
 static int fetch_bank(gmx_group* g, int stream, std::vector<uint8_t>& img) {

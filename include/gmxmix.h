@@ -166,6 +166,23 @@ int gmx_bank_copy(gmx_group* dst, int dst_stream, gmx_group* src, int src_stream
 /* Mixer::GetMemoryUsage (mixer.cpp:197-205). */
 int gmx_bank_memory_usage(gmx_group* g, int stream, int mixer, uint64_t* bytes);
 
+/* ==== Lock-step surface: all S streams advance one bit per step ================================
+ * S decoders on one GPU (coder/decoder.cpp:19-39: a decoder learns its bit from Predict's own
+ * result) step together: Predict for all streams, S arithmetic decoders on the host, Learn for all
+ * streams.  Each half is one hipGraph captured at creation (record uploads, the T = 1 kernel, the
+ * download of the S probabilities), so a step costs two graph launches instead of a dozen runtime
+ * calls.  Fill the host arrays of gmx_lockstep_batch (gmx_batch_predictions / _active_mask /
+ * _contexts: one record per stream), call gmx_lockstep_predict, read gmx_batch_p (and
+ * gmx_batch_outputs if created with GMX_BATCH_OUTPUTS), put the coded bits into gmx_batch_bits,
+ * call gmx_lockstep_learn (asynchronous; skip it for generation, runner-utils.cpp:199-209).
+ * Same floats as every other surface.  Destroy before the group. */
+typedef struct gmx_lockstep gmx_lockstep;
+int gmx_lockstep_create(gmx_lockstep** out, gmx_group* g, unsigned flags /* 0 or GMX_BATCH_OUTPUTS */);
+void gmx_lockstep_destroy(gmx_lockstep* ls);
+gmx_batch* gmx_lockstep_batch(gmx_lockstep* ls);
+int gmx_lockstep_predict(gmx_lockstep* ls);
+int gmx_lockstep_learn(gmx_lockstep* ls);
+
 /* ==== Indirect models =========================================
  * The producers of 82 of the mixers' 90 inputs: the reference's 41 `Indirect` objects
  * (models/indirect.h:11-34, constructed in predictor.cpp:78-120, :122-185, :210-250) and their

@@ -179,3 +179,64 @@ def test_per_bit_latency_report(gpu, capsys):
               f"every bit), {out[1, 8]:.1f} us/bit (contexts held 8 bits); in {where[2]}: {out[2, 1]:.1f} / "
               f"{out[2, 8]:.1f}; two launches: {out[0, 1]:.1f} / {out[0, 8]:.1f} us/bit")
     assert out[1, 8] < out[0, 8]
+
+
+@pytest.mark.parametrize("shape", ["stock", "general"])
+def test_lockstep_graphs_equal_oracle(gpu, oracle, shape):
+    """gmx_lockstep: every stream one bit per step, each half step one hipGraph -- the floats and the
+    state of the batched surface and the oracle; a batched launch in between, generation (no Learn)
+    at the end, two streams that stand at different bit counts."""
+    topo = topology.stock(90) if shape == "stock" else topology.Topology(
+        40, [(0, 64, 0.004)] * 5 + [(1, 16, 0.003)] * 3 + [(2, 1, 0.0005)], skip=(1,))
+    n, m = topo.n_inputs, topo.n_mixers
+    S, T = 5, 420
+    recs = [oracle.synth(n, m, T, seed=61 + s, ctx_mode=3, ctx_mod=5, zero_mod=6, bit_mode=1) for s in range(S)]
+    refs = []
+    for s in range(S):
+        ob = oracle.Bank(n, topo.skip, topo.mixers)
+        refs.append((ob,) + ob.run(*recs[s], nolearn_from=400))
+    g = gpu.MixerGroup(topo, S)
+    # stream 3 starts older than the others: its decay factors differ from the first step on
+    pre = oracle.synth(n, m, 57, seed=5, ctx_mode=3, ctx_mod=5, bit_mode=1)
+    ob3 = oracle.Bank(n, topo.skip, topo.mixers)
+    ob3.run(*pre)
+    g.import_(ob3.export_long(), ob3.export_short(), stream=3)
+    refs[3] = (ob3,) + ob3.run(*recs[3], nolearn_from=400)
+    ls = gpu.Lockstep(g, outputs=True)
+    b = ls.batch
+
+    def step(t, learn=True):
+        for s in range(S):
+            pred, act, ctx, bits = recs[s]
+            b.set_records(s, pred[t:t + 1], act[t:t + 1], ctx[t:t + 1], np.zeros(1, np.uint8))
+        p = ls.predict()
+        for s in range(S):
+            assert np.array_equal(u32(b.outputs[s, 0]), u32(refs[s][2][t])), (t, s)
+            assert np.float32(p[s]).view(np.uint32) == refs[s][1][t].view(np.uint32), (t, s)
+            b.bits[s, 0] = recs[s][3][t]
+        if learn:
+            ls.learn()
+
+    for t in range(0, 150):
+        step(t)
+    # bits 150..269 through the batched surface, then back to lock step
+    bb = gpu.Batch(g, 120, outputs=True, mask=True)
+    for s in range(S):
+        bb.set_records(s, *[a[150:270] for a in recs[s]])
+    bb.upload(120)
+    g.run(bb, 120, learn=True)
+    bb.download(120)
+    bb.wait()
+    for s in range(S):
+        assert np.array_equal(u32(bb.outputs[s, :120]), u32(refs[s][2][150:270]))
+    for t in range(270, 400):
+        step(t)
+    with pytest.raises(gpu.GmxError):
+        ls.learn()                                  # Learn twice for one Predict
+    for t in range(400, 420):
+        step(t, learn=False)                        # generation: Predict only
+    for s in range(S):
+        assert g.export(s) == (refs[s][0].export_long(), refs[s][0].export_short())
+    bb.close()
+    ls.close()
+    g.close()
