@@ -85,7 +85,8 @@ def main():
     ap.add_argument("--stock-pairs", action="store_true",
                     help="--config stock: the lane-pair kernel (gmx_wide.hip) instead of the generated streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-bits", type=int, default=4_000_000)
+    ap.add_argument("--cpu-sample-bits", type=int, default=20_000_000,
+                    help="bits of the same stream for the one-core reference (about 15 s of CPU work)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,7 +203,7 @@ def main():
         except Exception as e:
             sys.stderr.write(f"[bench] no PMC summary: {e}\n")
         if n_gpus == 1 and not args.no_cpu_baseline:
-            sample = args.cpu_sample_bits if topo.n_mixers == 1 else min(args.cpu_sample_bits, 400_000)
+            sample = args.cpu_sample_bits if topo.n_mixers == 1 else min(args.cpu_sample_bits, 1_500_000)
             out["cpu_baseline"] = cpu_baseline(topo, sample, args.ctx_mode, args.ctx_mod)
         print(json.dumps(out), flush=True)
     for b in ring:

@@ -423,6 +423,7 @@ extern "C" int gmx_group_reset(gmx_group* g) {
   HIPCHK(hipStreamSynchronize(g->stream));
   std::fill(g->steps.begin(), g->steps.end(), 0);
   std::fill(g->fwd_done.begin(), g->fwd_done.end(), 0);
+  for (gmx_lockstep* ls : g->locksteps) ls->predicted = false;
   return GMX_OK;
 }
 
@@ -582,6 +583,7 @@ static int prepare_decay(gmx_group* g, int s0, int ns, uint64_t T, int learn, gm
 static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint64_t T,
                       unsigned mode, float* kernel_ms) {
   if (T == 0) return GMX_OK;
+  for (gmx_lockstep* ls : g->locksteps) ls->predicted = false;  // the latch no longer belongs to their Predict
   gmx_group::DecaySlot* dec = nullptr;
   int rc = prepare_decay(g, s0, ns, T, (mode & GMX_MODE_LEARN) ? 1 : 0, &dec);
   if (rc) return rc;
@@ -1080,6 +1082,7 @@ extern "C" int gmx_bank_import(gmx_group* g, int stream, const void* long_buf, s
                    hipMemcpyHostToDevice));
   g->steps[stream] = sc[0];
   g->fwd_done[stream] = 0;
+  for (gmx_lockstep* ls : g->locksteps) ls->predicted = false;
   return GMX_OK;
 }
 
@@ -1108,6 +1111,7 @@ extern "C" int gmx_bank_copy(gmx_group* dst, int dst_stream, gmx_group* src, int
                    hipMemcpyDeviceToDevice));
   dst->steps[dst_stream] = src->steps[src_stream];
   dst->fwd_done[dst_stream] = 0;
+  for (gmx_lockstep* ls : dst->locksteps) ls->predicted = false;
   return GMX_OK;
 }
 
