@@ -1131,6 +1131,79 @@ extern "C" int gmx_bank_memory_usage(gmx_group* g, int stream, int mixer, uint64
   return GMX_OK;
 }
 
+
+// ---- transfers of a record batch beside the kernels (used by the Indirect and LSTM batches; the
+// mixer batches carry the same three events themselves) -----------------------------------------
+struct GmxXfer {
+  hipEvent_t ev_up = nullptr;    // behind the newest upload
+  hipEvent_t ev_dev = nullptr;   // behind the newest device-side use, on the bank's stream
+  hipEvent_t ev_down = nullptr;  // behind the newest download
+  bool up_rec = false, dev_rec = false, down_rec = false;
+};
+static int xfer_init(GmxXfer& x) {
+  HIPCHK(hipEventCreateWithFlags(&x.ev_up, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&x.ev_dev, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&x.ev_down, hipEventDisableTiming));
+  return GMX_OK;
+}
+static void xfer_free(GmxXfer& x) {
+  hipEvent_t evs[] = {x.ev_up, x.ev_dev, x.ev_down};
+  for (hipEvent_t e : evs)
+    if (e) (void)hipEventDestroy(e);
+  x = GmxXfer();
+}
+static int xfer_note_device_use(GmxXfer& x, hipStream_t main) {
+  HIPCHK(hipEventRecord(x.ev_dev, main));
+  x.dev_rec = true;
+  return GMX_OK;
+}
+// The stream an upload of `bytes` runs on: one of its own (created on demand) behind the last
+// device-side use of the batch, or the bank's stream for small ones.
+static int xfer_begin_upload(GmxXfer& x, hipStream_t main, hipStream_t* own, size_t bytes, hipStream_t* use) {
+  if (bytes < kBatchOwnStreamMin) {
+    *use = main;
+    return GMX_OK;
+  }
+  if (!*own) HIPCHK(hipStreamCreateWithFlags(own, hipStreamNonBlocking));
+  *use = *own;
+  if (x.dev_rec) HIPCHK(hipStreamWaitEvent(*use, x.ev_dev, 0));
+  return GMX_OK;
+}
+static int xfer_end_upload(GmxXfer& x, hipStream_t main, hipStream_t use) {
+  HIPCHK(hipEventRecord(x.ev_up, use));
+  x.up_rec = true;
+  if (use != main) HIPCHK(hipStreamWaitEvent(main, x.ev_up, 0));
+  return GMX_OK;
+}
+static int xfer_begin_download(GmxXfer& x, hipStream_t main, hipStream_t* own, size_t bytes, hipStream_t* use) {
+  if (bytes < kBatchOwnStreamMin) {
+    *use = main;
+    return GMX_OK;
+  }
+  if (!*own) HIPCHK(hipStreamCreateWithFlags(own, hipStreamNonBlocking));
+  *use = *own;
+  int rc = xfer_note_device_use(x, main);
+  if (rc) return rc;
+  HIPCHK(hipStreamWaitEvent(*use, x.ev_dev, 0));
+  return GMX_OK;
+}
+static int xfer_end_download(GmxXfer& x, hipStream_t use) {
+  HIPCHK(hipEventRecord(x.ev_down, use));
+  x.down_rec = true;
+  return GMX_OK;
+}
+// before a kernel overwrites the batch's result arrays
+static int xfer_before_run(GmxXfer& x, hipStream_t main) {
+  if (x.down_rec) HIPCHK(hipStreamWaitEvent(main, x.ev_down, 0));
+  return GMX_OK;
+}
+static int xfer_wait(GmxXfer& x) {
+  if (x.up_rec) HIPCHK(hipEventSynchronize(x.ev_up));
+  if (x.dev_rec) HIPCHK(hipEventSynchronize(x.ev_dev));
+  if (x.down_rec) HIPCHK(hipEventSynchronize(x.ev_down));
+  return GMX_OK;
+}
+
 #include "gmx_indirect.inc"
 #include "gmx_lstm.inc"
 

@@ -238,7 +238,7 @@ const float* gmx_ind_batch_predictions(gmx_ind_batch* b); /* [S][max_bits][2*n_m
 const uint8_t* gmx_ind_batch_active(gmx_ind_batch* b);    /* [S][max_bits][2*n_models] */
 int gmx_ind_batch_upload(gmx_ind_batch* b, uint64_t n_bits);
 int gmx_ind_batch_download(gmx_ind_batch* b, uint64_t n_bits);
-int gmx_ind_batch_wait(gmx_ind_batch* b);
+int gmx_ind_batch_wait(gmx_ind_batch* b);                  /* this batch's upload, runs, download (cf. gmx_batch_wait) */
 /* Device-side generator of the synthetic stream of oracle/gmx_ind_synth.h (byte-structured
  * contexts, ctx_mod[4] moduli); stream s is seeded with seed + s * 0x9E3779B97F4A7C15. */
 int gmx_ind_batch_fill_synthetic(gmx_ind_batch* b, uint64_t n_bits, uint64_t seed, uint64_t restart,
@@ -295,7 +295,7 @@ const uint8_t* gmx_lstm_batch_active(gmx_lstm_batch* b);       /* [S][max_bytes]
 const uint32_t* gmx_lstm_batch_contexts(gmx_lstm_batch* b);    /* [S][max_bytes] */
 int gmx_lstm_batch_upload(gmx_lstm_batch* b, uint64_t n_bytes);
 int gmx_lstm_batch_download(gmx_lstm_batch* b, uint64_t n_bytes);
-int gmx_lstm_batch_wait(gmx_lstm_batch* b);
+int gmx_lstm_batch_wait(gmx_lstm_batch* b);                /* this batch's upload, runs, download (cf. gmx_batch_wait) */
 /* LstmModel::Predict x 8 bits (+ LstmModel::Learn when learn != 0) for bytes [0, n_bytes) of every
  * stream. */
 int gmx_lstm_run(gmx_lstm* l, gmx_lstm_batch* b, uint64_t n_bytes, int learn, float* kernel_ms);
