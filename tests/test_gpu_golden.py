@@ -88,11 +88,25 @@ def test_gpu_matches_reference_predictor_trace(gpu, oracle):
     assert oracle.encode(bits, b.p[0]) == oracle.encode(bits, p_ref.view(np.float32))
     # and bit by bit through Predict()/Learn()
     g2 = gpu.MixerGroup(topo, 1)
-    for t in range(400):
+    for t in range(T):
         idx = np.nonzero(act[t])[0].astype(np.int32)
         p, out = g2.forward(pred[t], idx, ctx[t])
         assert np.array_equal(out.view(np.uint32), outs_ref[t]), t
         assert np.float32(p).view(np.uint32) == p_ref[t]
         g2.learn(bits[t])
+    assert g2.export(0) == (lb, sb)
+    # ... and through the lock-step graphs (the surface for many decoders at once)
+    g3 = gpu.MixerGroup(topo, 2)
+    ls = gpu.Lockstep(g3, outputs=True)
+    for t in range(T):
+        for s in range(2):
+            ls.batch.set_records(s, pred[t:t + 1], act[t:t + 1], ctx[t:t + 1], bits[t:t + 1])
+        p = ls.predict()
+        assert np.array_equal(ls.batch.outputs[1, 0].view(np.uint32), outs_ref[t]), t
+        assert p[0].view(np.uint32) == p_ref[t] and p[1].view(np.uint32) == p_ref[t]
+        ls.learn()
+    assert g3.export(0) == (lb, sb) and g3.export(1) == (lb, sb)
+    ls.close()
     g.close()
     g2.close()
+    g3.close()
