@@ -67,7 +67,7 @@ __device__ unsigned long long gmx_lstm_prof[16];
 namespace {
 
 constexpr int NI = GMX_L_NI, NO = GMX_L_NO, NC = GMX_L_NC, H = GMX_L_H, LIN = GMX_L_LIN, LINP = GMX_L_LINP,
-              W = GMX_L_W, HID = GMX_L_HID, CP = GMX_L_CP;
+              HID = GMX_L_HID, CP = GMX_L_CP;
 constexpr float kLearningRate = 0.03f, kClip = 10.0f;
 constexpr uint32_t kUpdateLimit = 3000;
 

@@ -120,7 +120,7 @@ template <int N, int HALF, bool HAS_MASK>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
   using SH = WideShape<N, HALF>;
-  constexpr int kN = SH::kN, kHalf = SH::kHalf, kNPad = SH::kNPad, kMW = SH::kMW, kQ = SH::kQ, kUp = SH::kUp,
+  constexpr int kHalf = SH::kHalf, kNPad = SH::kNPad, kMW = SH::kMW, kQ = SH::kQ, kUp = SH::kUp,
                 kQU = SH::kQU, kPitch = SH::kPitch, kStageSmall = SH::kStageSmall;
   __shared__ __attribute__((aligned(16))) float xin[kNPad + 4];
   __shared__ __attribute__((aligned(16))) float stage[SH::kStageFloats];
