@@ -160,8 +160,20 @@ struct GmxIndRunArgs {
 #define GMX_L_CP 64
 #define GMX_L_HP 100
 
+// The [input][cell] matrices of a gate (weights, update_, m_, v_): the 256 symbol rows one row of CP
+// cells each; the 307 layer-input rows in blocks of four -- [block][cell][4] -- so that a lane's
+// chain over the inputs reads 16 bytes per load (4-byte loads kept the texture path busy for 16
+// cycles per 200 bytes: 9 us of a byte's 32 went there).
+#define GMX_L_LINB 77     // blocks of four layer-input rows (the last one holds three)
+#define GMX_L_MAT_FLOATS (GMX_L_NO * GMX_L_CP + GMX_L_LINB * GMX_L_CP * 4)
+__host__ __device__ inline uint64_t gmx_l_mat(int j, int c) {  // float offset of (input j, cell c)
+  return j < GMX_L_NO ? (uint64_t)j * GMX_L_CP + (uint64_t)c
+                      : (uint64_t)GMX_L_NO * GMX_L_CP +
+                            ((uint64_t)((j - GMX_L_NO) >> 2) * GMX_L_CP + (uint64_t)c) * 4 + (uint64_t)((j - GMX_L_NO) & 3);
+}
+
 struct GmxLstmGateOff {   // float offsets inside a bank
-  uint64_t weights, update, m, v;                 // [W][CP]   (row = input index, column = cell)
+  uint64_t weights, update, m, v;                 // GMX_L_MAT_FLOATS each, indexed by gmx_l_mat
   uint64_t gamma, gamma_u, gamma_m, gamma_v, beta, beta_u, beta_m, beta_v, error;  // [CP]
   uint64_t state, norm;                           // [H][CP]
   uint64_t ivar;                                  // [H]

@@ -168,14 +168,23 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
         const GmxLstmGateOff& g = dv.gate[wave];
         const float* w = B + g.weights;
         float f = w[(uint64_t)last_byte * CP + lane];
+        // blocks of four layer inputs, 16 bytes per lane and load; a stretch = kB blocks in flight
+        constexpr int kB = (kStretch + 3) / 4;
+        const float* wl = w + gmx_l_mat(NO, lane);
 #pragma unroll 1
-        for (int j0 = 0; j0 < LIN; j0 += kStretch) {
-          float wv[kStretch];
+        for (int q0 = 0; q0 < GMX_L_LINB; q0 += kB) {
+          float4 wq[kB];
 #pragma unroll
-          for (int u = 0; u < kStretch; ++u) wv[u] = w[(uint64_t)(NO + (j0 + u < LIN ? j0 + u : LIN - 1)) * CP + lane];
+          for (int u = 0; u < kB; ++u)
+            wq[u] = *(const float4*)(wl + (uint64_t)(q0 + u < GMX_L_LINB ? q0 + u : GMX_L_LINB - 1) * (CP * 4));
 #pragma unroll
-          for (int u = 0; u < kStretch; ++u)
-            if (j0 + u < LIN) f += L.xin[j0 + u] * wv[u];
+          for (int u = 0; u < kB; ++u) {
+            const int j = 4 * (q0 + u);
+            if (j + 0 < LIN) f += L.xin[j + 0] * wq[u].x;
+            if (j + 1 < LIN) f += L.xin[j + 1] * wq[u].y;
+            if (j + 2 < LIN) f += L.xin[j + 2] * wq[u].z;
+            if (j + 3 < LIN) f += L.xin[j + 3] * wq[u].w;
+          }
         }
         L.nrm[wave][lane] = f;
       }
@@ -419,7 +428,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
             // transpose_ (lstm-layer.cpp:300-304): only a checkpoint ever reads this copy, the
             // chains below take the recurrent weights from the matrix itself (unchanged until Adam)
             for (int j = 0; j < HID; ++j)
-              (B + g.transpose)[(uint64_t)j * CP + lane] = (B + g.weights)[(uint64_t)(NO + NI + j) * CP + lane];
+              (B + g.transpose)[(uint64_t)j * CP + lane] = (B + g.weights)[gmx_l_mat(NO + NI + j, lane)];
           }
           err = L.act[wave][lane];
           nv = (B + g.norm + (uint64_t)ep * CP)[lane];
@@ -450,11 +459,11 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
         if (wave < 3 && lane < NC) {
           const GmxLstmGateOff& g = dv.gate[wave];
           if (ep > 0) {  // through the recurrent weights (transpose_ is a snapshot of them)
-            const float* wr = B + g.weights + (uint64_t)(NO + NI + lane) * CP;
+            const float* wr = B + g.weights + gmx_l_mat(NO + NI + lane, 0);  // this row's cells are 4 floats apart
             float f = 0.0f;
             float rv[NC];
 #pragma unroll
-            for (int j = 0; j < NC; ++j) rv[j] = wr[j];
+            for (int j = 0; j < NC; ++j) rv[j] = wr[4 * j];
 #pragma unroll
             for (int j = 0; j < NC; ++j) f += L.act[wave][j] * rv[j];
             L.fsum[wave][lane] = f;
@@ -515,7 +524,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
             constexpr int kMine = kTileRows / 4;
             auto row_ix = [&](int u) {
               const int r = r0 + wave + 4 * u;
-              return (uint64_t)(NO + (r < LIN ? r : LIN - 1)) * CP + cl;
+              return gmx_l_mat(NO + (r < LIN ? r : LIN - 1), cl);
             };
             float am = (B + go.m)[row_ix(0)], av = (B + go.v)[row_ix(0)], aw = (B + go.weights)[row_ix(0)];
 #pragma unroll
@@ -538,7 +547,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
               }
               const int r = r0 + wave + 4 * u;
               if (r < LIN && lane < NC) {
-                const uint64_t ix = (uint64_t)(NO + r) * CP + lane;
+                const uint64_t ix = gmx_l_mat(NO + r, lane);
                 float m = am * beta1;
                 m += (1.0f - beta1) * acc;
                 float v = av * beta2;
