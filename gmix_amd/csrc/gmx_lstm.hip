@@ -144,6 +144,26 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
 #ifdef GMX_LSTM_PROF
   unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
 #endif
+  // per-lane copies of what every byte reads and only a backward pass changes (layer-norm gain and
+  // bias of this wave's gate), of the cell state, and of the NEXT byte's PPM input: requested by an
+  // inline-asm load while the current byte is computed, collected by the s_waitcnt at the end of the
+  // same loop iteration (on the other side of the back edge the compiler could copy the register
+  // before the data is in)
+  float gam = 0.0f, bet = 0.0f, cst = 0.0f, ppm_n = 0.0f;
+  if (wave < 3 && lane < NC) {
+    gam = (B + dv.gate[wave].gamma)[lane];
+    bet = (B + dv.gate[wave].beta)[lane];
+  }
+  if (tid < NC) cst = (B + dv.state)[tid];
+  auto ppm_request = [&](uint64_t nn) {
+    const float* p = ppm_s + (nn < a.n_bytes ? nn : a.n_bytes - 1) * NI + tid;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(ppm_n) : "v"(p) : "memory");
+  };
+  auto ppm_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(ppm_n)); };
+  if (a.phases & 1u) {
+    ppm_request(0);
+    ppm_landed();
+  }
   for (uint64_t n = 0; n < a.n_bytes; ++n) {
     const uint32_t byte = bytes_s[n];
     STAMP(0);
@@ -153,10 +173,11 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       const uint32_t e = epoch, le = l_epoch;
       float* const lin = B + dv.layer_input + (uint64_t)e * LINP;
       // SetInput + the recurrent part of the layer input (lstm.cpp:45-50, :98-100)
-      L.xin[tid] = ppm_s[n * NI + tid];
+      L.xin[tid] = ppm_n;
+      ppm_request(n + 1);
       if (tid < NC) L.xin[NI + tid] = L.hid[tid];
       if (tid == 0) L.xin[LIN - 1] = 1.0f;
-      if (tid < NC) (B + dv.last_state + (uint64_t)le * CP)[tid] = (B + dv.state)[tid];  // lstm-layer.cpp:200
+      if (tid < NC) (B + dv.last_state + (uint64_t)le * CP)[tid] = cst;  // lstm-layer.cpp:200
       __syncthreads();
       for (int j = tid; j < LIN; j += 256) {
         lin[j] = L.xin[j];
@@ -209,7 +230,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
         const GmxLstmGateOff& g = dv.gate[wave];
         const float nv = L.nrm[wave][lane] * L.red[wave];
         (B + g.norm + (uint64_t)le * CP)[lane] = nv;
-        float st = nv * (B + g.gamma)[lane] + (B + g.beta)[lane];
+        float st = nv * gam + bet;
         st = wave == 1 ? gmx_tanhf(st) : gmx_logistic_tab(st, L.exptab);  // lstm-layer.cpp:205-211
         (B + g.state + (uint64_t)le * CP)[lane] = st;
         L.act[wave][lane] = st;
@@ -218,9 +239,10 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       if (tid < NC) {  // lstm-layer.cpp:212-217
         const float f = L.act[0][tid];
         const float igs = 1.0f - f;
-        float st = (B + dv.state)[tid] * f;
+        float st = cst * f;
         st = st + L.act[1][tid] * igs;
         const float ts = gmx_tanhf(st);
+        cst = st;
         (B + dv.input_gate_state + (uint64_t)le * CP)[tid] = igs;
         (B + dv.state)[tid] = st;
         (B + dv.tanh_state + (uint64_t)le * CP)[tid] = ts;
@@ -331,6 +353,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       coded = 1;
     }
     if (!a.learn || !(a.phases & 4u)) {
+      if (a.phases & 1u) ppm_landed();
       __syncthreads();
       continue;
     }
@@ -434,7 +457,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
           nv = (B + g.norm + (uint64_t)ep * CP)[lane];
           (B + g.beta_u)[lane] += err;
           (B + g.gamma_u)[lane] += err * nv;
-          err *= (B + g.gamma)[lane] * (B + g.ivar)[ep];
+          err *= gam * (B + g.ivar)[ep];
           L.nrm[wave][lane] = err * nv;
         }
         __syncthreads();
@@ -597,6 +620,10 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
         }
       }
       __syncthreads();
+      if (wave < 3 && lane < NC) {  // Adam has moved the layer-norm parameters
+        gam = (B + dv.gate[wave].gamma)[lane];
+        bet = (B + dv.gate[wave].beta)[lane];
+      }
       ++bptt_done;
     }
     STAMP(9);  // deferred accumulation + Adam (backward bytes)
@@ -613,6 +640,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
 #pragma unroll
       for (int j = 0; j < HID; ++j) dst[(uint64_t)j * NO + tid] = sv[j] - le * L.hid[j];
     }
+    if (a.phases & 1u) ppm_landed();
     __syncthreads();
   }
   // state back to the bank
