@@ -107,8 +107,8 @@ def main():
 
     import gmix_amd
     topo, workload = make_topology(args.config)
-    if args.streams is None:  # what fills the chip for the shape: one wave per SIMD for the 3-layer banks
-        args.streams = 3072 if args.config == "single" else 1024
+    if args.streams is None:  # what fills the chip for the shape: one wave per SIMD (4 one-mixer streams per wave)
+        args.streams = 4096 if args.config == "single" else 1024
     S, T = args.streams, args.bits
     steps = args.steps if args.steps is not None else max(1, -(-100_000_000 // (S * T)))  # 10^8 bits
 
