@@ -39,7 +39,8 @@
 // load-then-add rounds per gate chain; the whole chain at once, 307, spills) with two workgroups
 // per CU give 1.14e7 bytes/s at 4096 streams and 7.9e6 at 256, stretches of 77 with three per CU
 // 1.06e7 and 6.65e6.  Both builds exist; GMX_LSTM_BUILD=3 in the environment picks the second.
-// (Tried and dropped: a dense [input][50] pitch for the gate matrices instead of [input][64] -- 22%
+// (Tried and dropped: the non-temporal hint on the weight and ring-slot accesses -- unlike the mixer
+// rows they ARE reused from L2 / the memory-side cache: 5-12% slower; a dense [input][50] pitch for the gate matrices instead of [input][64] -- 22%
 // fewer bytes, but rows that no longer start on a cache line: 15-25% slower at every stream count.)
 #ifndef GMX_LSTM_STRETCH
 #define GMX_LSTM_STRETCH 77

@@ -72,7 +72,7 @@ struct WideShape {
 };
 
 __device__ __forceinline__ void wide_ld16(gmx_f4& d, const void* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(d) : "v"(p) : "memory");
 }
 __device__ __forceinline__ void wide_ld4(uint32_t& d, const void* p) {
   asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory");
@@ -94,7 +94,7 @@ __device__ __forceinline__ void wide_dma16(uint64_t sbase, uint32_t voff, uint32
   uint32_t sm0;
   asm volatile(
       "s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %3, %2\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %0"
+      "global_load_lds_dwordx4 %3, %2 nt\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %0"
       : "=&s"(sv), "=&s"(sm0)
       : "s"(sbase), "v"(voff), "s"(mask), "s"(lds_byte)
       : "memory");
@@ -104,7 +104,7 @@ __device__ __forceinline__ void wide_st16(uint64_t sbase, uint32_t voff, const g
   uint64_t sv;
   asm volatile(
       "s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\t"
-      "global_store_dwordx4 %2, %3, %1\n\ts_mov_b64 exec, %0"
+      "global_store_dwordx4 %2, %3, %1 nt\n\ts_mov_b64 exec, %0"
       : "=&s"(sv)
       : "s"(sbase), "v"(voff), "v"(v), "s"(mask)
       : "memory");
