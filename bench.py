@@ -154,13 +154,15 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    S_all = S * n_gpus
     if dist is not None:
         from gmix_amd import shard
         elapsed = shard.max_over_ranks(elapsed, dist, device="cuda")
+        S_all = shard.sum_over_ranks(S, dist, device="cuda")  # a rank with less free HBM runs fewer streams
     kernel_ms = [gpu_ms / steps]
 
     if rank == 0:
-        bits_per_step = S * T * n_gpus
+        bits_per_step = S_all * T
         value = bits_per_step * steps / elapsed
         avg_ms = sum(kernel_ms) / len(kernel_ms)
         # rows move when a gate context changes: every bit (ctx-mode 0/1) or every 8th bit (2/3)

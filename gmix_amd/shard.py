@@ -38,3 +38,13 @@ def max_over_ranks(value, dist=None, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def sum_over_ranks(value, dist=None, device="cpu"):
+    """SUM all-reduce of an integer (streams per rank can differ if a rank had less free HBM)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return int(value)
+    import torch
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())

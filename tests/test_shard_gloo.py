@@ -35,8 +35,9 @@ def _worker(rank, world, port, n_streams, q):
     assert all(shard.stream_owner(s, world) == rank for s in mine)
     sizes = shard.gather_u64({s: _stream_size(s) for s in mine}, n_streams, dist)
     slowest = shard.max_over_ranks(1.0 + rank, dist)
+    total = shard.sum_over_ranks(4096 - 1024 * rank, dist)   # a rank that had to run fewer streams
     dist.barrier()
-    q.put((rank, mine, sizes.tolist(), slowest))
+    q.put((rank, mine, sizes.tolist(), slowest, total))
     dist.destroy_process_group()
 
 
@@ -53,11 +54,12 @@ def test_two_ranks_shard_and_gather():
         p.join(timeout=60)
         assert p.exitcode == 0
     expect = [_stream_size(s) for s in range(n_streams)]
-    owned = sorted(s for _, mine, _, _ in got for s in mine)
+    owned = sorted(s for _, mine, _, _, _ in got for s in mine)
     assert owned == list(range(n_streams))          # every stream exactly once
-    for rank, mine, sizes, slowest in got:
+    for rank, mine, sizes, slowest, total in got:
         assert sizes == expect                       # every rank sees every size
         assert slowest == 2.0                        # MAX over ranks
+        assert total == 4096 + 3072                  # SUM over ranks
 
 
 def test_shard_helpers_single_process():
