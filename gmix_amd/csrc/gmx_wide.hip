@@ -66,8 +66,11 @@ struct WideShape {
            : h < 32 + kL0 ? (kL0 + h - 32) * kPitch
            : h == kFinLane ? kStageSmall + kL1 * kPitchS : 0;
   }
+  // Lower halves are weights throughout; upper half k holds kUp input weights and k cascade
+  // weights, the rest of its stored 16-byte pieces is zero padding in HBM and in the registers alike
+  // (never loaded, never stored, never anything but zero).
   static constexpr int stage_lanes(int h) {
-    return (h < kL0 || (h >= 32 && h < 32 + kL0)) ? kQ : ((h < 32 || h == kFinLane) ? kQS : 0);
+    return h < kL0 ? kQ : (h >= 32 && h < 32 + kL0) ? (kUp + (h - 32) + 3) / 4 : ((h < 32 || h == kFinLane) ? kQS : 0);
   }
 };
 
@@ -131,6 +134,9 @@ gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
   const uint64_t T = a.T;
   if (T == 0) return;
   if (lane < 32) s_tab[lane] = gmx_exp2f_tab[lane];
+  // the staging image starts out zero: the padding pieces of a row are not fetched, so what the
+  // owner reads there must be the zeros the write-back path put (or these)
+  for (int i = 4 * lane; i < SH::kStageFloats; i += 256) *(gmx_f4*)(stage + i) = gmx_f4{0.f, 0.f, 0.f, 0.f};
   const bool do_learn = (a.mode & GMX_MODE_LEARN) != 0;
   uint8_t* const bank = a.banks + (uint64_t)s * tp->bank_bytes;
 
