@@ -90,25 +90,23 @@ __device__ __forceinline__ uint32_t wide_lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
 // One coalesced piece of a row, HBM -> LDS without a VGPR round trip: the lanes of `mask` move 16
-// bytes each from sbase + voff to LDS[lds_byte + 16 * lane] (LDS base in M0, saved and restored).
-// An empty mask issues nothing.
+// bytes each from sbase + voff to LDS[lds_byte + 16 * lane] (LDS base in M0).  An empty mask issues
+// nothing.  Called only where all 64 lanes of the wave are active (uniform control flow, blocks of
+// one full wave), so exec goes back to all ones instead of being saved; M0 is left clobbered.
 __device__ __forceinline__ void wide_dma16(uint64_t sbase, uint32_t voff, uint32_t lds_byte, uint64_t mask) {
-  uint64_t sv;
-  uint32_t sm0;
   asm volatile(
-      "s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %3, %2 nt\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %0"
-      : "=&s"(sv), "=&s"(sm0)
+      "s_mov_b64 exec, %2\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %0 nt\n\ts_mov_b64 exec, -1"
+      :
       : "s"(sbase), "v"(voff), "s"(mask), "s"(lds_byte)
-      : "memory");
+      : "memory", "m0");
 }
 // ... and back: the lanes of `mask` store 16 bytes each to sbase + voff.
 __device__ __forceinline__ void wide_st16(uint64_t sbase, uint32_t voff, const gmx_f4& v, uint64_t mask) {
-  uint64_t sv;
   asm volatile(
-      "s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\t"
-      "global_store_dwordx4 %2, %3, %1 nt\n\ts_mov_b64 exec, %0"
-      : "=&s"(sv)
+      "s_mov_b64 exec, %3\n\t"
+      "global_store_dwordx4 %1, %2, %0 nt\n\ts_mov_b64 exec, -1"
+      :
       : "s"(sbase), "v"(voff), "v"(v), "s"(mask)
       : "memory");
 }
