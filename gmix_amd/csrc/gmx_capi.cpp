@@ -609,7 +609,7 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
   if (kernel_ms) HIPCHK(hipEventRecord(g->ev0, g->stream));
   // Banks that are a single layer-0 mixer take the register-resident throughput kernel
   // (gmx_single.hip); everything else, and every per-bit call, the general kernel.
-  const bool single = g->topo.m == 1 && g->topo.n <= 256 && !a.mask && (mode & GMX_MODE_PREDICT) &&
+  const bool single = g->topo.m == 1 && g->topo.n <= 256 && (mode & GMX_MODE_PREDICT) &&
                       !(mode & GMX_MODE_LATCH) && !g->force_general;
   // The reference's own shape (90 inputs, 24/8/1, one skip input) runs with its rows in
   // registers (gmx_stock.hip); it only needs the small part of the LDS image.

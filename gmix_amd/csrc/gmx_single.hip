@@ -72,6 +72,7 @@ template <int K>
 struct GmxSlot {
   gmx_f4 w[K];
   gmx_f4 x[K];
+  uint32_t mk[K];  // HAS_MASK: the active-mask word that covers this lane's quad of chunk k
   uint64_t rs;   // MixerData::steps of the row (long-term-memory.h:29)
   uint32_t row;
   uint32_t bit;
@@ -99,6 +100,13 @@ __device__ __forceinline__ void gmx_wait_slot(GmxSlot<4>& a) {
                : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(a.x[0]), "+v"(a.x[1]),
                  "+v"(a.x[2]), "+v"(a.x[3]), "+v"(a.rs), "+v"(a.bit), "+v"(a.dec)
                : "n"(N));
+}
+// The mask words of a slot ride on the same wait: pinned right behind it.
+template <int K>
+__device__ __forceinline__ void gmx_pin_mask(GmxSlot<K>& a) {
+  if (K == 1) asm volatile("" : "+v"(a.mk[0]));
+  if (K == 2) asm volatile("" : "+v"(a.mk[0]), "+v"(a.mk[1 % K]));
+  if (K == 4) asm volatile("" : "+v"(a.mk[0]), "+v"(a.mk[1 % K]), "+v"(a.mk[2 % K]), "+v"(a.mk[3 % K]));
 }
 // Pins older, already released values behind the preceding wait (asm volatile statements keep
 // their order).
@@ -150,14 +158,14 @@ __device__ __forceinline__ float gmx_chain(const GmxSlot<K>& c, int lane) {
 // K     : float4 chunks per lane (n_inputs <= 4*LPS*K)
 // NSLOT : register slots in the prefetch ring (bits in flight, the current one included)
 // FULL  : n_inputs == n_pad == stride == 4*LPS*K -- no ragged edges (the benchmark shape)
-template <int LPS, int K, int NSLOT, bool FULL, bool WANT_OUT, bool LEARN>
+template <int LPS, int K, int NSLOT, bool FULL, bool WANT_OUT, bool LEARN, bool HAS_MASK>
 __global__ void __launch_bounds__(64)
 gmx_single_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
   constexpr int G = 64 / LPS;
   constexpr int CH = 4 * LPS;  // elements per chunk
   // vector-memory instructions per bit, in issue order: p (+out) stores, K row stores + the
-  // row-step store (LEARN), 2K+3 refill loads, 1 context load.
-  constexpr int VM_PER_BIT = 1 + (WANT_OUT ? 1 : 0) + (LEARN ? K + 1 : 0) + 2 * K + 3 + 1;
+  // row-step store (LEARN), 2K+3 refill loads (+K mask words), 1 context load.
+  constexpr int VM_PER_BIT = 1 + (WANT_OUT ? 1 : 0) + (LEARN ? K + 1 : 0) + 2 * K + 3 + (HAS_MASK ? K : 0) + 1;
   // At the top of bit t the youngest data needed are slot t+1's, loaded during bit
   // t+1-NSLOT and followed by that bit's context load and all of bits t+2-NSLOT .. t-1.
   constexpr int VM_WAIT = 1 + (NSLOT - 2) * VM_PER_BIT;
@@ -191,6 +199,8 @@ gmx_single_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
   const uint32_t* const ctx_s = a.ctx + (uint64_t)rec * RS;
   const uint8_t* const bits_s = a.bits + (uint64_t)rec * RS;
   const float* const dec_s = a.decay + (uint64_t)a.decay_idx[li] * T;
+  const int MW = tp->mask_words;
+  const uint32_t* const mask_s = HAS_MASK ? a.mask + (uint64_t)rec * RS * MW : nullptr;
   float* const p_s = a.p_out + (uint64_t)rec * RS;
   float* const oa_s = WANT_OUT ? a.out_all + (uint64_t)rec * RS : nullptr;
 
@@ -227,9 +237,30 @@ gmx_single_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
         gmx_ld16<0>(d.x[k], e < NPAD ? xr + CH * k : xr - 4 * l);
       }
     }
+    if (HAS_MASK) {
+      // the active_models word of each of this lane's quads (a quad never straddles a word)
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int e = CH * k + 4 * l;
+        gmx_ld4(d.mk[k], mask_s + tt * (uint64_t)MW + (e < NPAD ? (e >> 5) : 0));
+      }
+    }
     gmx_ld8(d.rs, rstab + d.row);
     gmx_ld1(d.bit, bits_s + tt);
     gmx_ld4(d.dec, dec_s + tt);
+  };
+  // Only active_models are visited (mixer.cpp:57-59): a silent slot contributes nothing to the sum
+  // and its weight does not move -- both exactly what a zero input gives.
+  auto mask_inputs = [&](GmxSlot<K>& d) {
+    if (!HAS_MASK) return;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t b = d.mk[k] >> ((uint32_t)(CH * k + 4 * l) & 31u);
+      d.x[k].x = (b & 1u) ? d.x[k].x : 0.f;
+      d.x[k].y = (b & 2u) ? d.x[k].y : 0.f;
+      d.x[k].z = (b & 4u) ? d.x[k].z : 0.f;
+      d.x[k].w = (b & 8u) ? d.x[k].w : 0.f;
+    }
   };
   // Ragged shapes: zero what lies outside the row / the inputs (after the data has landed).
   auto trim = [&](GmxSlot<K>& d) {
@@ -264,9 +295,11 @@ gmx_single_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
 #pragma unroll
   for (int k = 0; k < NSLOT; ++k) {
     gmx_wait_slot<0>(sl[k]);
+    if (HAS_MASK) gmx_pin_mask(sl[k]);
     gmx_pin(sl[k].rs, sl[k].bit, sl[k].dec, ctxq[k]);
   }
   trim(sl[0]);
+  mask_inputs(sl[0]);
   float acc_cur = gmx_chain<K, LPS>(sl[0], lane);
 
   for (uint64_t t0 = 0; t0 < T; t0 += NSLOT) {
@@ -278,8 +311,10 @@ gmx_single_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
       GmxSlot<K>& nx = sl[(k + 1) % NSLOT];
       // ---- release slot t+1 (rows, inputs) and with it everything older ------------------
       gmx_wait_slot<VM_WAIT>(nx);
+      if (HAS_MASK) gmx_pin_mask(nx);
       gmx_pin(c.rs, c.bit, c.dec, ctxq[k]);
       trim(nx);
+      mask_inputs(nx);
       // ---- speculative Mixer::Predict chain of bit t+1, spread over the stages of bit t ----
       float acc_nxt = gmx_chain_piece<K, LPS>(nx, 0, 0.f, lane);
       // ---- finish Mixer::Predict of bit t ---------------------------------------------
@@ -372,23 +407,32 @@ gmx_single_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
   }
 }
 
-template <int LPS, int K, int NSLOT, bool FULL>
-static hipError_t launch_kf(const GmxTopoDev* tp_dev, const GmxRunArgs& a, hipStream_t stream) {
+template <int LPS, int K, int NSLOT, bool FULL, bool HAS_MASK>
+static hipError_t launch_kfm(const GmxTopoDev* tp_dev, const GmxRunArgs& a, hipStream_t stream) {
   constexpr int G = 64 / LPS;
   const dim3 grid((a.n_streams + G - 1) / G), block(64);
   const bool learn = (a.mode & GMX_MODE_LEARN) != 0;
   if (a.out_all) {
     if (learn)
-      hipLaunchKernelGGL((gmx_single_kernel<LPS, K, NSLOT, FULL, true, true>), grid, block, 0, stream, tp_dev, a);
+      hipLaunchKernelGGL((gmx_single_kernel<LPS, K, NSLOT, FULL, true, true, HAS_MASK>), grid, block, 0, stream, tp_dev, a);
     else
-      hipLaunchKernelGGL((gmx_single_kernel<LPS, K, NSLOT, FULL, true, false>), grid, block, 0, stream, tp_dev, a);
+      hipLaunchKernelGGL((gmx_single_kernel<LPS, K, NSLOT, FULL, true, false, HAS_MASK>), grid, block, 0, stream, tp_dev, a);
   } else {
     if (learn)
-      hipLaunchKernelGGL((gmx_single_kernel<LPS, K, NSLOT, FULL, false, true>), grid, block, 0, stream, tp_dev, a);
+      hipLaunchKernelGGL((gmx_single_kernel<LPS, K, NSLOT, FULL, false, true, HAS_MASK>), grid, block, 0, stream, tp_dev, a);
     else
-      hipLaunchKernelGGL((gmx_single_kernel<LPS, K, NSLOT, FULL, false, false>), grid, block, 0, stream, tp_dev, a);
+      hipLaunchKernelGGL((gmx_single_kernel<LPS, K, NSLOT, FULL, false, false, HAS_MASK>), grid, block, 0, stream, tp_dev, a);
   }
   return hipGetLastError();
+}
+template <int LPS, int K, int NSLOT, bool FULL>
+static hipError_t launch_kf(const GmxTopoDev* tp_dev, const GmxRunArgs& a, hipStream_t stream) {
+  // batches with an active mask: one slot less in the ring where the mask words would push the
+  // counted wait past the 6-bit vmcnt
+  constexpr int VM_M = 1 + 1 + (K + 1) + 2 * K + 3 + K + 1;
+  constexpr int NS_M = (1 + (NSLOT - 2) * VM_M <= 63) ? NSLOT : NSLOT - 1;
+  return a.mask ? launch_kfm<LPS, K, NS_M, FULL, true>(tp_dev, a, stream)
+                : launch_kfm<LPS, K, NSLOT, FULL, false>(tp_dev, a, stream);
 }
 
 template <int LPS, int K, int NSLOT>
@@ -398,8 +442,8 @@ static hipError_t launch_k(const GmxTopoDev* tp_dev, const GmxRunArgs& a, bool f
               : launch_kf<LPS, K, NSLOT, false>(tp_dev, a, stream);
 }
 
-// Eligible banks: exactly one layer-0 mixer, n_inputs <= 256, batch without an active mask,
-// batched Predict(+Learn) mode.  The host side checks that before calling.
+// Eligible banks: exactly one layer-0 mixer, n_inputs <= 256, batched Predict(+Learn) mode, with or
+// without an active mask.  The host side checks that before calling.
 // `variant` picks the lane mapping: 0 = default for the shape, 16/32/64 = lanes per stream.
 extern "C" hipError_t gmx_launch_single_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args,
                                                int n_inputs, int variant, hipStream_t stream) {

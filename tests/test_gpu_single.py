@@ -1,5 +1,5 @@
-"""The register-resident throughput kernel (gmx_single.hip: banks that are one layer-0 mixer,
-batches without an active mask) against the oracle and against the general kernel."""
+"""The register-resident throughput kernel (gmx_single.hip: banks that are one layer-0 mixer, batches
+with or without an active mask) against the oracle and against the general kernel."""
 import ctypes as C
 
 import numpy as np
@@ -21,14 +21,14 @@ def set_variant(g, lanes_per_stream):
     assert g.L.gmx_debug_single_variant(g.h, lanes_per_stream) == 0
 
 
-def run_gpu(gpu, topo, streams, chunk, learn=True, force_general=False, outputs=True, variant=0):
+def run_gpu(gpu, topo, streams, chunk, learn=True, force_general=False, outputs=True, variant=0, mask=False):
     S, T = len(streams), len(streams[0][3])
     g = gpu.MixerGroup(topo, S)
     set_variant(g, variant)
     if force_general:
         g.L.gmx_debug_force_general.argtypes = [C.c_void_p, C.c_int]
         g.L.gmx_debug_force_general(g.h, 1)
-    b = gpu.Batch(g, chunk, outputs=outputs, mask=False)
+    b = gpu.Batch(g, chunk, outputs=outputs, mask=mask)
     P = np.zeros((S, T), np.float32)
     O = np.zeros((S, T, 1), np.float32)
     for t0 in range(0, T, chunk):
@@ -139,3 +139,30 @@ def test_full_size_streams_sampled_against_oracle(gpu, oracle):
         visits = rec[:, 4:12].copy().view(np.uint64).ravel()
         assert visits.sum() == steps and visits.max() == max_steps
     g.close()
+
+
+@pytest.mark.parametrize("n,table,T,chunk,S,kw,variant", [
+    (256, 1 << 12, 2200, 700, 5, dict(ctx_mode=3, ctx_mod=6, zero_mod=3, bit_mode=1), 0),
+    (256, 4, 2600, 1300, 3, dict(ctx_mode=1, ctx_mod=2, zero_mod=2, bit_mode=1), 32),   # shrink, half the slots silent
+    (90, 1000, 1500, 1500, 4, dict(ctx_mode=3, ctx_mod=7, zero_mod=5), 16),              # K = 2, ragged
+    (40, 17, 900, 400, 6, dict(ctx_mode=1, ctx_mod=50, zero_mod=3, bit_mode=1), 0),      # K = 1, ragged
+    (129, 300, 800, 800, 2, dict(ctx_mode=1, ctx_mod=9, zero_mod=4, bit_mode=1), 165),   # deeper ring requested
+])
+def test_single_kernel_with_active_mask(gpu, oracle, n, table, T, chunk, S, kw, variant):
+    """Batches that carry an active_models mask: silent slots keep their stale values in the
+    prediction records (the reference leaves them on the blackboard) and must neither add to the
+    sum nor move their weights."""
+    topo = topology.single(n, table, 0.005)
+    streams = [oracle.synth(n, 1, T, seed=GOLD + 77 * s, **kw) for s in range(S)]
+    assert any((st[1] == 0).any() and (st[0][st[1] == 0] != 0).any() for st in streams)   # stale, nonzero, silent
+    g, P, O = run_gpu(gpu, topo, streams, chunk, variant=variant, mask=True)
+    g2, P2, O2 = run_gpu(gpu, topo, streams, chunk, force_general=True, mask=True)
+    assert beq(P, P2) and beq(O, O2)
+    for s in range(S):
+        ob = oracle.Bank(n, topo.skip, topo.mixers)
+        p_ref, o_ref = ob.run(*streams[s])
+        assert beq(O[s], o_ref), (s, np.argwhere(O[s].view(np.uint32) != o_ref.view(np.uint32))[:3])
+        assert beq(P[s], p_ref)
+        assert g.export(s) == (ob.export_long(), ob.export_short()) == g2.export(s)
+    g.close()
+    g2.close()
