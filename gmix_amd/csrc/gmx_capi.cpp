@@ -77,6 +77,81 @@ static int hip_fail(hipError_t e, const char* what) {
     if (e_ != hipSuccess) return hip_fail(e_, #call);  \
   } while (0)
 
+static const size_t kBatchOwnStreamMin = 256u * 1024u;  // bytes from which a transfer takes a stream of its own
+// ---- transfers of a record batch beside the kernels (BASELINE configs[3]: "pinned hipMemcpyAsync
+// double-buffered host->device probability batches"): uploads and downloads of big batches run on
+// streams of their own; three events per batch order them against the kernels that use it ------
+struct GmxXfer {
+  hipEvent_t ev_up = nullptr;    // behind the newest upload
+  hipEvent_t ev_dev = nullptr;   // behind the newest device-side use, on the bank's stream
+  hipEvent_t ev_down = nullptr;  // behind the newest download
+  bool up_rec = false, dev_rec = false, down_rec = false;
+};
+static int xfer_init(GmxXfer& x) {
+  HIPCHK(hipEventCreateWithFlags(&x.ev_up, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&x.ev_dev, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&x.ev_down, hipEventDisableTiming));
+  return GMX_OK;
+}
+static void xfer_free(GmxXfer& x) {
+  hipEvent_t evs[] = {x.ev_up, x.ev_dev, x.ev_down};
+  for (hipEvent_t e : evs)
+    if (e) (void)hipEventDestroy(e);
+  x = GmxXfer();
+}
+static int xfer_note_device_use(GmxXfer& x, hipStream_t main) {
+  HIPCHK(hipEventRecord(x.ev_dev, main));
+  x.dev_rec = true;
+  return GMX_OK;
+}
+// The stream an upload of `bytes` runs on: one of its own (created on demand) behind the last
+// device-side use of the batch, or the bank's stream for small ones.
+static int xfer_begin_upload(GmxXfer& x, hipStream_t main, hipStream_t* own, size_t bytes, hipStream_t* use) {
+  if (bytes < kBatchOwnStreamMin) {
+    *use = main;
+    return GMX_OK;
+  }
+  if (!*own) HIPCHK(hipStreamCreateWithFlags(own, hipStreamNonBlocking));
+  *use = *own;
+  if (x.dev_rec) HIPCHK(hipStreamWaitEvent(*use, x.ev_dev, 0));
+  return GMX_OK;
+}
+static int xfer_end_upload(GmxXfer& x, hipStream_t main, hipStream_t use) {
+  HIPCHK(hipEventRecord(x.ev_up, use));
+  x.up_rec = true;
+  if (use != main) HIPCHK(hipStreamWaitEvent(main, x.ev_up, 0));
+  return GMX_OK;
+}
+static int xfer_begin_download(GmxXfer& x, hipStream_t main, hipStream_t* own, size_t bytes, hipStream_t* use) {
+  if (bytes < kBatchOwnStreamMin) {
+    *use = main;
+    return GMX_OK;
+  }
+  if (!*own) HIPCHK(hipStreamCreateWithFlags(own, hipStreamNonBlocking));
+  *use = *own;
+  int rc = xfer_note_device_use(x, main);
+  if (rc) return rc;
+  HIPCHK(hipStreamWaitEvent(*use, x.ev_dev, 0));
+  return GMX_OK;
+}
+static int xfer_end_download(GmxXfer& x, hipStream_t use) {
+  HIPCHK(hipEventRecord(x.ev_down, use));
+  x.down_rec = true;
+  return GMX_OK;
+}
+// before a kernel overwrites the batch's result arrays
+static int xfer_before_run(GmxXfer& x, hipStream_t main) {
+  if (x.down_rec) HIPCHK(hipStreamWaitEvent(main, x.ev_down, 0));
+  return GMX_OK;
+}
+static int xfer_wait(GmxXfer& x) {
+  if (x.up_rec) HIPCHK(hipEventSynchronize(x.ev_up));
+  if (x.dev_rec) HIPCHK(hipEventSynchronize(x.ev_dev));
+  if (x.down_rec) HIPCHK(hipEventSynchronize(x.ev_down));
+  return GMX_OK;
+}
+
+
 struct gmx_group {
   int device = 0;
   int S = 0;
@@ -151,11 +226,7 @@ struct gmx_batch {
   uint8_t* h_bits = nullptr;
   float* h_p = nullptr;
   float* h_out = nullptr;
-  // ordering of this batch's transfers against the kernels that use its device arrays
-  hipEvent_t ev_up = nullptr;    // behind the newest upload (on the group's upload stream)
-  hipEvent_t ev_dev = nullptr;   // behind the newest device-side use (on the group's stream)
-  hipEvent_t ev_down = nullptr;  // behind the newest download (on the group's download stream)
-  bool up_rec = false, dev_rec = false, down_rec = false;
+  GmxXfer x;  // ordering of this batch's transfers against the kernels that use its device arrays
 };
 
 // lock-step stepping of all streams, one hipGraph per half step (gmx_lockstep.inc)
@@ -163,6 +234,7 @@ struct gmx_lockstep {
   gmx_group* g = nullptr;
   gmx_batch* b = nullptr;        // one record per stream; owned
   float* dec_host = nullptr;     // pinned [S]: float(0.9 / pow(1e-7 * steps_ + 0.8, 0.8)) of every stream's next learn
+  uint8_t* bits_host = nullptr;  // pinned [S]: the coded bits as they were when gmx_lockstep_learn was called
   float* dec_dev = nullptr;      // [S]
   uint32_t* idx_dev = nullptr;   // [S] identity: stream s uses table row s
   hipGraph_t g_predict = nullptr, g_learn = nullptr;
@@ -605,7 +677,10 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
   a.stream_base = s0;
   a.rec_base = rec0;
   a.n_streams = ns;
-  if (b->down_rec) HIPCHK(hipStreamWaitEvent(g->stream, b->ev_down, 0));  // p of the previous run is out
+  {
+    int rcx = xfer_before_run(b->x, g->stream);  // p of the previous run is out
+    if (rcx) return rcx;
+  }
   if (kernel_ms) HIPCHK(hipEventRecord(g->ev0, g->stream));
   // Banks that are a single layer-0 mixer take the register-resident throughput kernel
   // (gmx_single.hip); everything else, and every per-bit call, the general kernel.
@@ -634,7 +709,7 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
                                   g->topo.mx[g->topo.l0 - 1].stride, g->stream));
   HIPCHK(hipEventRecord(dec->done, g->stream));
   dec->busy = true;
-  if (b->ev_dev) {
+  {
     int rcn = batch_note_device_use(b);
     if (rcn) return rcn;
   }
@@ -666,9 +741,7 @@ static void batch_free(gmx_batch* b) {
   void* hv[] = {b->h_pred, b->h_mask, b->h_ctx, b->h_bits, b->h_p, b->h_out};
   for (void* p : hv)
     if (p) (void)hipHostFree(p);
-  hipEvent_t evs[] = {b->ev_up, b->ev_dev, b->ev_down};
-  for (hipEvent_t e : evs)
-    if (e) (void)hipEventDestroy(e);
+  xfer_free(b->x);
   delete b;
 }
 
@@ -699,10 +772,14 @@ static int batch_alloc(gmx_batch** out, gmx_group* g, int S, uint64_t max_bits, 
   BCHK(hipMalloc((void**)&b->d_bits, R));
   BCHK(hipMalloc((void**)&b->d_p, R * sizeof(float)));
   if (flags & GMX_BATCH_OUTPUTS) BCHK(hipMalloc((void**)&b->d_out, R * t.m * sizeof(float)));
-  BCHK(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
-  BCHK(hipEventCreateWithFlags(&b->ev_dev, hipEventDisableTiming));
-  BCHK(hipEventCreateWithFlags(&b->ev_down, hipEventDisableTiming));
 #undef BCHK
+  {
+    int rcx = xfer_init(b->x);
+    if (rcx) {
+      batch_free(b);
+      return rcx;
+    }
+  }
   g->batches.push_back(b);
   *out = b;
   return GMX_OK;
@@ -764,14 +841,8 @@ static hipError_t copy_rows(void* dst, const void* src, size_t elem_bytes, size_
   return hipMemcpy2DAsync(dst, pitch, src, pitch, width, (size_t)b->S, kind, st);
 }
 
-static const size_t kBatchOwnStreamMin = 256u * 1024u;  // bytes from which a transfer takes a stream of its own
-
 // Device-side work on the group's stream has just been queued that reads or writes b's arrays.
-static int batch_note_device_use(gmx_batch* b) {
-  HIPCHK(hipEventRecord(b->ev_dev, b->g->stream));
-  b->dev_rec = true;
-  return GMX_OK;
-}
+static int batch_note_device_use(gmx_batch* b) { return xfer_note_device_use(b->x, b->g->stream); }
 
 // The copies run on the group's upload stream: behind the last kernel that used this batch's
 // arrays, beside whatever else the group's stream is running (the kernel of ANOTHER batch, in a
@@ -784,23 +855,19 @@ extern "C" int gmx_batch_upload(gmx_batch* b, uint64_t n_bits) {
   HIPCHK(hipSetDevice(g->device));
   if (!gmx_batch_predictions(b) || !gmx_batch_contexts(b) || !gmx_batch_bits(b)) return GMX_ERR_NOMEM;
   if ((b->flags & GMX_BATCH_MASK) && !gmx_batch_active_mask(b)) return GMX_ERR_NOMEM;
-  // small transfers stay on the group's stream: the cross-stream hand-shakes would cost more than
-  // the copies could ever overlap
+  // (small transfers stay on the group's stream: the cross-stream hand-shakes would cost more than
+  // the copies could ever overlap)
   const size_t bytes = (size_t)b->S * n_bits * ((size_t)t.n_pad * 4 + (size_t)t.m * 4 + 1 +
                                                 ((b->flags & GMX_BATCH_MASK) ? (size_t)t.mask_words * 4 : 0));
-  const bool own = bytes >= kBatchOwnStreamMin;
-  if (own && !g->up_stream) HIPCHK(hipStreamCreateWithFlags(&g->up_stream, hipStreamNonBlocking));
-  hipStream_t st = own ? g->up_stream : g->stream;
-  if (own && b->dev_rec) HIPCHK(hipStreamWaitEvent(st, b->ev_dev, 0));
+  hipStream_t st = nullptr;
+  int rc = xfer_begin_upload(b->x, g->stream, &g->up_stream, bytes, &st);
+  if (rc) return rc;
   HIPCHK(copy_rows(b->d_pred, b->h_pred, 4, t.n_pad, b, n_bits, hipMemcpyHostToDevice, st));
   if (b->flags & GMX_BATCH_MASK)
     HIPCHK(copy_rows(b->d_mask, b->h_mask, 4, t.mask_words, b, n_bits, hipMemcpyHostToDevice, st));
   HIPCHK(copy_rows(b->d_ctx, b->h_ctx, 4, t.m, b, n_bits, hipMemcpyHostToDevice, st));
   HIPCHK(copy_rows(b->d_bits, b->h_bits, 1, 1, b, n_bits, hipMemcpyHostToDevice, st));
-  HIPCHK(hipEventRecord(b->ev_up, st));
-  b->up_rec = true;
-  if (own) HIPCHK(hipStreamWaitEvent(g->stream, b->ev_up, 0));
-  return GMX_OK;
+  return xfer_end_upload(b->x, g->stream, st);
 }
 
 // Behind everything queued on the group's stream so far, on the group's download stream.
@@ -813,20 +880,13 @@ extern "C" int gmx_batch_download(gmx_batch* b, uint64_t n_bits) {
   if (!gmx_batch_p(b)) return GMX_ERR_NOMEM;
   if ((b->flags & GMX_BATCH_OUTPUTS) && !gmx_batch_outputs(b)) return GMX_ERR_NOMEM;
   const size_t bytes = (size_t)b->S * n_bits * (4 + ((b->flags & GMX_BATCH_OUTPUTS) ? (size_t)t.m * 4 : 0));
-  const bool own = bytes >= kBatchOwnStreamMin;
-  if (own && !g->down_stream) HIPCHK(hipStreamCreateWithFlags(&g->down_stream, hipStreamNonBlocking));
-  hipStream_t st = own ? g->down_stream : g->stream;
-  if (own) {
-    int rc = batch_note_device_use(b);
-    if (rc) return rc;
-    HIPCHK(hipStreamWaitEvent(st, b->ev_dev, 0));
-  }
+  hipStream_t st = nullptr;
+  int rc = xfer_begin_download(b->x, g->stream, &g->down_stream, bytes, &st);
+  if (rc) return rc;
   HIPCHK(copy_rows(b->h_p, b->d_p, 4, 1, b, n_bits, hipMemcpyDeviceToHost, st));
   if (b->flags & GMX_BATCH_OUTPUTS)
     HIPCHK(copy_rows(b->h_out, b->d_out, 4, t.m, b, n_bits, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipEventRecord(b->ev_down, st));
-  b->down_rec = true;
-  return GMX_OK;
+  return xfer_end_download(b->x, st);
 }
 
 // The host waits for THIS batch's queued work: its upload, the device work that used it, its
@@ -834,10 +894,7 @@ extern "C" int gmx_batch_download(gmx_batch* b, uint64_t n_bits) {
 extern "C" int gmx_batch_wait(gmx_batch* b) {
   if (!b || !b->g) return GMX_ERR_INVALID;
   HIPCHK(hipSetDevice(b->g->device));
-  if (b->up_rec) HIPCHK(hipEventSynchronize(b->ev_up));
-  if (b->dev_rec) HIPCHK(hipEventSynchronize(b->ev_dev));
-  if (b->down_rec) HIPCHK(hipEventSynchronize(b->ev_down));
-  return GMX_OK;
+  return xfer_wait(b->x);
 }
 
 extern "C" int gmx_batch_fill_synthetic(gmx_batch* b, uint64_t n_bits, uint64_t seed,
@@ -876,7 +933,6 @@ extern "C" int gmx_batch_fill_synthetic(gmx_batch* b, uint64_t n_bits, uint64_t 
   a.bit_mode = bit_mode;
   a.ctx_mod = ctx_mod;
   a.zero_mod = zero_mod;
-  if (b->up_rec) HIPCHK(hipStreamWaitEvent(b->g->stream, b->ev_up, 0));
   HIPCHK(gmx_launch_synth_kernel(&a, b->g->stream));
   return batch_note_device_use(b);
 }
@@ -1131,78 +1187,6 @@ extern "C" int gmx_bank_memory_usage(gmx_group* g, int stream, int mixer, uint64
   return GMX_OK;
 }
 
-
-// ---- transfers of a record batch beside the kernels (used by the Indirect and LSTM batches; the
-// mixer batches carry the same three events themselves) -----------------------------------------
-struct GmxXfer {
-  hipEvent_t ev_up = nullptr;    // behind the newest upload
-  hipEvent_t ev_dev = nullptr;   // behind the newest device-side use, on the bank's stream
-  hipEvent_t ev_down = nullptr;  // behind the newest download
-  bool up_rec = false, dev_rec = false, down_rec = false;
-};
-static int xfer_init(GmxXfer& x) {
-  HIPCHK(hipEventCreateWithFlags(&x.ev_up, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&x.ev_dev, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&x.ev_down, hipEventDisableTiming));
-  return GMX_OK;
-}
-static void xfer_free(GmxXfer& x) {
-  hipEvent_t evs[] = {x.ev_up, x.ev_dev, x.ev_down};
-  for (hipEvent_t e : evs)
-    if (e) (void)hipEventDestroy(e);
-  x = GmxXfer();
-}
-static int xfer_note_device_use(GmxXfer& x, hipStream_t main) {
-  HIPCHK(hipEventRecord(x.ev_dev, main));
-  x.dev_rec = true;
-  return GMX_OK;
-}
-// The stream an upload of `bytes` runs on: one of its own (created on demand) behind the last
-// device-side use of the batch, or the bank's stream for small ones.
-static int xfer_begin_upload(GmxXfer& x, hipStream_t main, hipStream_t* own, size_t bytes, hipStream_t* use) {
-  if (bytes < kBatchOwnStreamMin) {
-    *use = main;
-    return GMX_OK;
-  }
-  if (!*own) HIPCHK(hipStreamCreateWithFlags(own, hipStreamNonBlocking));
-  *use = *own;
-  if (x.dev_rec) HIPCHK(hipStreamWaitEvent(*use, x.ev_dev, 0));
-  return GMX_OK;
-}
-static int xfer_end_upload(GmxXfer& x, hipStream_t main, hipStream_t use) {
-  HIPCHK(hipEventRecord(x.ev_up, use));
-  x.up_rec = true;
-  if (use != main) HIPCHK(hipStreamWaitEvent(main, x.ev_up, 0));
-  return GMX_OK;
-}
-static int xfer_begin_download(GmxXfer& x, hipStream_t main, hipStream_t* own, size_t bytes, hipStream_t* use) {
-  if (bytes < kBatchOwnStreamMin) {
-    *use = main;
-    return GMX_OK;
-  }
-  if (!*own) HIPCHK(hipStreamCreateWithFlags(own, hipStreamNonBlocking));
-  *use = *own;
-  int rc = xfer_note_device_use(x, main);
-  if (rc) return rc;
-  HIPCHK(hipStreamWaitEvent(*use, x.ev_dev, 0));
-  return GMX_OK;
-}
-static int xfer_end_download(GmxXfer& x, hipStream_t use) {
-  HIPCHK(hipEventRecord(x.ev_down, use));
-  x.down_rec = true;
-  return GMX_OK;
-}
-// before a kernel overwrites the batch's result arrays
-static int xfer_before_run(GmxXfer& x, hipStream_t main) {
-  if (x.down_rec) HIPCHK(hipStreamWaitEvent(main, x.ev_down, 0));
-  return GMX_OK;
-}
-static int xfer_wait(GmxXfer& x) {
-  if (x.up_rec) HIPCHK(hipEventSynchronize(x.ev_up));
-  if (x.dev_rec) HIPCHK(hipEventSynchronize(x.ev_dev));
-  if (x.down_rec) HIPCHK(hipEventSynchronize(x.ev_down));
-  return GMX_OK;
-}
 
 #include "gmx_indirect.inc"
 #include "gmx_lstm.inc"
