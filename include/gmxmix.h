@@ -135,7 +135,10 @@ const float* gmx_batch_outputs(gmx_batch* b);   /* NULL without GMX_BATCH_OUTPUT
  * batch: an upload starts when the last run of THIS batch is done and overlaps whatever runs on
  * other batches (double buffering: run(A); upload(B); run(B); download(A); wait(A); refill A ...);
  * everything queued on the group after gmx_batch_upload returns sees the new records.  A download
- * follows everything queued on the group so far.  wait = this batch's upload, runs and download. */
+ * follows everything queued on the group so far.  wait = this batch's upload, runs and download.
+ * The batch's host arrays are read (upload) and written (download) when the copies execute, not when
+ * the calls return: leave them alone between gmx_batch_upload / gmx_batch_download and the
+ * gmx_batch_wait that follows. */
 int gmx_batch_upload(gmx_batch* b, uint64_t n_bits);    /* async H2D of the first n_bits of every stream */
 int gmx_batch_download(gmx_batch* b, uint64_t n_bits);  /* async D2H of p (and outputs) */
 int gmx_batch_wait(gmx_batch* b);                       /* host waits for this batch's queued work */
@@ -174,7 +177,8 @@ int gmx_bank_memory_usage(gmx_group* g, int stream, int mixer, uint64_t* bytes);
  * calls.  Fill the host arrays of gmx_lockstep_batch (gmx_batch_predictions / _active_mask /
  * _contexts: one record per stream), call gmx_lockstep_predict, read gmx_batch_p (and
  * gmx_batch_outputs if created with GMX_BATCH_OUTPUTS), put the coded bits into gmx_batch_bits,
- * call gmx_lockstep_learn (asynchronous; skip it for generation, runner-utils.cpp:199-209).
+ * call gmx_lockstep_learn (asynchronous -- it works on a private copy of the bits, the array is the
+ * caller's again when it returns; skip it for generation, runner-utils.cpp:199-209).
  * Same floats as every other surface.  Destroy before the group. */
 typedef struct gmx_lockstep gmx_lockstep;
 int gmx_lockstep_create(gmx_lockstep** out, gmx_group* g, unsigned flags /* 0 or GMX_BATCH_OUTPUTS */);
