@@ -278,6 +278,11 @@ class Lockstep:
     def learn(self):
         check(self.L.gmx_lockstep_learn(self.h), "gmx_lockstep_learn")
 
+    def learn_predict(self):
+        """Learn the bits of the step before and predict the next records, one graph."""
+        check(self.L.gmx_lockstep_learn_predict(self.h), "gmx_lockstep_learn_predict")
+        return self.batch.p[:, 0]
+
     def close(self):
         if getattr(self, "h", None):
             self.batch.h = None

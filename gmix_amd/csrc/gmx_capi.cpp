@@ -237,8 +237,8 @@ struct gmx_lockstep {
   uint8_t* bits_host = nullptr;  // pinned [S]: the coded bits as they were when gmx_lockstep_learn was called
   float* dec_dev = nullptr;      // [S]
   uint32_t* idx_dev = nullptr;   // [S] identity: stream s uses table row s
-  hipGraph_t g_predict = nullptr, g_learn = nullptr;
-  hipGraphExec_t x_predict = nullptr, x_learn = nullptr;
+  hipGraph_t g_predict = nullptr, g_learn = nullptr, g_step = nullptr;
+  hipGraphExec_t x_predict = nullptr, x_learn = nullptr, x_step = nullptr;  // step = learn, then predict
   bool predicted = false;
 };
 
@@ -1326,6 +1326,43 @@ extern "C" int gmx_debug_per_bit_latency(gmx_group* g, int stream, int n, int ct
   clock_gettime(CLOCK_MONOTONIC, &b);
   *us_per_bit = ((b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3) / n;
   return GMX_OK;
+}
+
+// Wall-clock cost of n lock-step steps (Predict for all streams, the probabilities on the host, Learn
+// for all streams) through gmx_lockstep_*, with new gate contexts every ctx_hold steps.
+extern "C" int gmx_debug_lockstep_latency(gmx_group* g, int n, int ctx_hold, int fused, double* us_per_step) {
+  if (!g || n <= 0 || ctx_hold <= 0 || !us_per_step) return GMX_ERR_INVALID;
+  gmx_lockstep* ls = nullptr;
+  int rc = gmx_lockstep_create(&ls, g, 0);
+  if (rc) return rc;
+  gmx_batch* b = gmx_lockstep_batch(ls);
+  const GmxTopoDev& t = g->topo;
+  float* pred = gmx_batch_predictions(b);
+  uint32_t* ctx = gmx_batch_contexts(b);
+  uint8_t* bits = gmx_batch_bits(b);
+  const float* p = gmx_batch_p(b);
+  uint64_t x = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&x]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  for (int s = 0; s < g->S; ++s)
+    for (int k = 0; k < t.n; ++k)
+      pred[(size_t)s * t.n_pad + k] = (float)((int64_t)(rnd() >> 40) - (1 << 23)) * (1.0f / (1 << 21));
+  timespec a, e;
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  for (int i = 0; i < n && rc == GMX_OK; ++i) {
+    if (i % ctx_hold == 0)
+      for (size_t k = 0; k < (size_t)g->S * t.m; ++k) ctx[k] = (uint32_t)rnd();
+    // the first step predicts; every later one learns the bits of the step before and predicts, as
+    // one graph (fused == 0: two graphs per step)
+    rc = (fused && i > 0) ? gmx_lockstep_learn_predict(ls) : gmx_lockstep_predict(ls);
+    if (rc) break;
+    for (int s = 0; s < g->S; ++s) bits[s] = p[s] > 0.5f ? 1 : 0;  // stands in for S arithmetic decoders
+    if (!fused || i + 1 == n) rc = gmx_lockstep_learn(ls);
+  }
+  if (rc == GMX_OK) rc = gmx_group_sync(g);
+  clock_gettime(CLOCK_MONOTONIC, &e);
+  *us_per_step = ((e.tv_sec - a.tv_sec) * 1e6 + (e.tv_nsec - a.tv_nsec) * 1e-3) / n;
+  gmx_lockstep_destroy(ls);
+  return rc;
 }
 
 extern "C" int gmx_debug_math_probe(int device, const float* x, float* y, uint64_t n, int what) {

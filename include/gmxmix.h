@@ -172,7 +172,7 @@ int gmx_bank_memory_usage(gmx_group* g, int stream, int mixer, uint64_t* bytes);
 /* ==== Lock-step surface: all S streams advance one bit per step ================================
  * S decoders on one GPU (coder/decoder.cpp:19-39: a decoder learns its bit from Predict's own
  * result) step together: Predict for all streams, S arithmetic decoders on the host, Learn for all
- * streams.  Each half is one hipGraph captured at creation (record uploads, the T = 1 kernel, the
+ * streams.  Each half -- and the pair learn + next predict -- is one hipGraph captured at creation (record uploads, the T = 1 kernel, the
  * download of the S probabilities), so a step costs two graph launches instead of a dozen runtime
  * calls.  Fill the host arrays of gmx_lockstep_batch (gmx_batch_predictions / _active_mask /
  * _contexts: one record per stream), call gmx_lockstep_predict, read gmx_batch_p (and
@@ -186,6 +186,9 @@ void gmx_lockstep_destroy(gmx_lockstep* ls);
 gmx_batch* gmx_lockstep_batch(gmx_lockstep* ls);
 int gmx_lockstep_predict(gmx_lockstep* ls);
 int gmx_lockstep_learn(gmx_lockstep* ls);
+/* learn (bits in gmx_batch_bits) and the next predict (records in the host arrays) as one graph: the
+ * step of S decoders once their first prediction is out.  Returns with the new probabilities. */
+int gmx_lockstep_learn_predict(gmx_lockstep* ls);
 
 /* ==== Indirect models =========================================
  * The producers of 82 of the mixers' 90 inputs: the reference's 41 `Indirect` objects

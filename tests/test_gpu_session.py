@@ -174,8 +174,21 @@ def test_per_bit_latency_report(gpu, capsys):
         L.gmx_debug_mailbox_on_device(g.h, 0 if sessions == 2 else 1, 0, C.byref(on_dev))
         where[sessions] = "device memory" if on_dev.value else "pinned host memory"
         g.close()
+    steps = {}
+    for S in (1, 256, 1024):
+        g = gpu.MixerGroup(topo, S)
+        g.L.gmx_debug_lockstep_latency.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        us = C.c_double()
+        for fused in (0, 1):
+            assert g.L.gmx_debug_lockstep_latency(g.h, 100, 8, fused, C.byref(us)) == 0
+            assert g.L.gmx_debug_lockstep_latency(g.h, 1000, 8, fused, C.byref(us)) == 0
+            steps[S, fused] = us.value
+        g.close()
     with capsys.disabled():
-        print(f"\n[per-bit Predict+Learn, C ABI] session, commands in {where[1]}: {out[1, 1]:.1f} us/bit (new rows "
+        print(f"\n[lock-step Predict / host round trip / Learn, C ABI] one hipGraph per half step: "
+              + ", ".join(f"S = {S}: {steps[S, 0]:.1f}" for S in (1, 256, 1024)) + " us/step; learn + next predict as one graph: "
+              + ", ".join(f"S = {S}: {steps[S, 1]:.1f}" for S in (1, 256, 1024)) + " us/step")
+        print(f"[per-bit Predict+Learn, C ABI] session, commands in {where[1]}: {out[1, 1]:.1f} us/bit (new rows "
               f"every bit), {out[1, 8]:.1f} us/bit (contexts held 8 bits); in {where[2]}: {out[2, 1]:.1f} / "
               f"{out[2, 8]:.1f}; two launches: {out[0, 1]:.1f} / {out[0, 8]:.1f} us/bit")
     assert out[1, 8] < out[0, 8]
@@ -229,8 +242,24 @@ def test_lockstep_graphs_equal_oracle(gpu, oracle, shape):
     bb.wait()
     for s in range(S):
         assert np.array_equal(u32(bb.outputs[s, :120]), u32(refs[s][2][150:270]))
+    # bits 270..399: learn and the next predict as one graph
+    def fill(t):
+        for s in range(S):
+            pred, act, ctx, bits = recs[s]
+            b.set_records(s, pred[t:t + 1], act[t:t + 1], ctx[t:t + 1], np.zeros(1, np.uint8))
+
+    fill(270)
+    p = ls.predict()
     for t in range(270, 400):
-        step(t)
+        for s in range(S):
+            assert np.array_equal(u32(b.outputs[s, 0]), u32(refs[s][2][t])), (t, s)
+            assert np.float32(p[s]).view(np.uint32) == refs[s][1][t].view(np.uint32), (t, s)
+        if t + 1 < 400:
+            fill(t + 1)                              # set_records zeroes the bits ...
+        for s in range(S):
+            b.bits[s, 0] = recs[s][3][t]             # ... so the coded bits go in afterwards
+        p = ls.learn_predict() if t + 1 < 400 else None
+    ls.learn()
     with pytest.raises(gpu.GmxError):
         ls.learn()                                  # Learn twice for one Predict
     for t in range(400, 420):
