@@ -92,14 +92,15 @@ __device__ __forceinline__ uint32_t wide_lds_addr(const void* p) {
 // One coalesced piece of a row, HBM -> LDS without a VGPR round trip: the lanes of `mask` move 16
 // bytes each from sbase + voff to LDS[lds_byte + 16 * lane] (LDS base in M0).  An empty mask issues
 // nothing.  Called only where all 64 lanes of the wave are active (uniform control flow, blocks of
-// one full wave), so exec goes back to all ones instead of being saved; M0 is left clobbered.
+// one full wave), so exec goes back to all ones instead of being saved; M0 is saved and restored.
 __device__ __forceinline__ void wide_dma16(uint64_t sbase, uint32_t voff, uint32_t lds_byte, uint64_t mask) {
+  uint32_t sm0;
   asm volatile(
-      "s_mov_b64 exec, %2\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %0 nt\n\ts_mov_b64 exec, -1"
-      :
+      "s_mov_b64 exec, %3\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, %1 nt\n\ts_mov_b32 m0, %0\n\ts_mov_b64 exec, -1"
+      : "=&s"(sm0)
       : "s"(sbase), "v"(voff), "s"(mask), "s"(lds_byte)
-      : "memory", "m0");
+      : "memory");
 }
 // ... and back: the lanes of `mask` store 16 bytes each to sbase + voff.
 __device__ __forceinline__ void wide_st16(uint64_t sbase, uint32_t voff, const gmx_f4& v, uint64_t mask) {
