@@ -153,6 +153,8 @@ def lib():
     L.gmx_lockstep_predict.argtypes = [vp]
     L.gmx_lockstep_learn.argtypes = [vp]
     L.gmx_lockstep_learn_predict.argtypes = [vp]
+    for name in ("gmx_group_set_cu_mask", "gmx_indirect_set_cu_mask", "gmx_lstm_set_cu_mask"):
+        getattr(L, name).argtypes = [vp, C.POINTER(u32), i32]
     L.gmx_debug_math_probe.argtypes = [i32, vp, vp, u64, i32]
     L.gmx_debug_math_range.argtypes = [i32, u64, u64, i32, C.POINTER(C.c_ulonglong)]
     _LIB = L
@@ -188,4 +190,5 @@ ABI_SYMBOLS = [
     "gmx_lstm_batch_active", "gmx_lstm_batch_contexts", "gmx_lstm_batch_upload", "gmx_lstm_batch_download",
     "gmx_lstm_batch_wait", "gmx_lstm_run", "gmx_lstm_forward", "gmx_lstm_perceive", "gmx_lstm_feed",
     "gmx_lstm_export", "gmx_lstm_import", "gmx_lstm_copy", "gmx_lstm_memory_usage",
+    "gmx_group_set_cu_mask", "gmx_indirect_set_cu_mask", "gmx_lstm_set_cu_mask",
 ]

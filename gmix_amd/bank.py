@@ -70,6 +70,12 @@ class MixerGroup:
         check(self.L.gmx_group_create(C.byref(h), C.byref(st), n_streams, device), "gmx_group_create")
         self.h = h
 
+    def set_cu_mask(self, words=None):
+        """Compute units this bank's kernels may use: 32-bit words, bit i = CU i (None: all)."""
+        w = list(words) if words else []
+        arr = (C.c_uint32 * max(1, len(w)))(*w)
+        check(self.L.gmx_group_set_cu_mask(self.h, arr, len(w)), "gmx_group_set_cu_mask")
+
     def close(self):
         if getattr(self, "h", None):
             self.L.gmx_group_destroy(self.h)

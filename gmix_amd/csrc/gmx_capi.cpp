@@ -1328,6 +1328,42 @@ extern "C" int gmx_debug_per_bit_latency(gmx_group* g, int stream, int n, int ct
   return GMX_OK;
 }
 
+// Compute-unit share of a bank's kernels: its main stream is re-created with a CU mask
+// (hipExtStreamCreateWithCUMask; n_words 32-bit words, bit i = CU i), so that kernels of different
+// banks that cannot share a SIMD (the 512-register mixer waves, the LSTM workgroups) run side by side
+// on disjoint CUs instead of one after the other.  n_words == 0: back to all CUs.
+static int stream_with_cu_mask(hipStream_t* st, const uint32_t* mask, int n_words) {
+  hipStream_t fresh = nullptr;
+  if (n_words > 0)
+    HIPCHK(hipExtStreamCreateWithCUMask(&fresh, (uint32_t)n_words, mask));
+  else
+    HIPCHK(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+  if (*st) {
+    (void)hipStreamSynchronize(*st);
+    (void)hipStreamDestroy(*st);
+  }
+  *st = fresh;
+  return GMX_OK;
+}
+extern "C" int gmx_group_set_cu_mask(gmx_group* g, const uint32_t* mask, int n_words) {
+  if (!g || n_words < 0 || (n_words > 0 && !mask)) return GMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(g->device));
+  int rc = sessions_close(g, false);
+  if (rc) return rc;
+  if (!g->locksteps.empty()) return GMX_ERR_STATE;  // their graphs are bound to the old stream
+  return stream_with_cu_mask(&g->stream, mask, n_words);
+}
+extern "C" int gmx_indirect_set_cu_mask(gmx_indirect* ib, const uint32_t* mask, int n_words) {
+  if (!ib || n_words < 0 || (n_words > 0 && !mask)) return GMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(ib->device));
+  return stream_with_cu_mask(&ib->stream, mask, n_words);
+}
+extern "C" int gmx_lstm_set_cu_mask(gmx_lstm* l, const uint32_t* mask, int n_words) {
+  if (!l || n_words < 0 || (n_words > 0 && !mask)) return GMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(l->device));
+  return stream_with_cu_mask(&l->stream, mask, n_words);
+}
+
 // Wall-clock cost of n lock-step steps (Predict for all streams, the probabilities on the host, Learn
 // for all streams) through gmx_lockstep_*, with new gate contexts every ctx_hold steps.
 extern "C" int gmx_debug_lockstep_latency(gmx_group* g, int n, int ctx_hold, int fused, double* us_per_step) {

@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--bytes", type=int, default=200)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--lstm-cus", type=int, default=16,
+                    help="CUs per XCD (of 32) the LSTM kernels get; the mixers and Indirect models get the rest")
+    ap.add_argument("--mask-layout", default="xcd", help="xcd: CU i of XCD x is mask bit 32x+i; flat: the first CUs")
     args = ap.parse_args()
     import gmix_amd
     import goldenlib
@@ -36,6 +39,17 @@ def main():
     lg = gmix_amd.LstmGroup(S)
     ig = gmix_amd.IndirectGroup(models, z["ns_next"], z["rm_next"], S, slots=slots)
     mg = gmix_amd.MixerGroup(topology.stock(90), S)
+    if args.lstm_cus:
+        n = args.lstm_cus
+        if args.mask_layout == "xcd":
+            lm = [(1 << n) - 1] * 8
+        else:
+            bits = (1 << (8 * n)) - 1
+            lm = [(bits >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+        rest = [(~w) & 0xFFFFFFFF for w in lm]
+        lg.set_cu_mask(lm)          # the LSTM on `n` CUs of every XCD ...
+        ig.set_cu_mask(rest)        # ... the Indirect models and the mixers on the others: side by side
+        mg.set_cu_mask(rest)
     # two sets of downstream records: the LSTM works on step k+1 while the mixers still read step k's
     lb = gmix_amd.LstmBatch(lg, NB)
     ibs = [gmix_amd.IndirectBatch(ig, T) for _ in range(2)]
@@ -72,7 +86,7 @@ def main():
         "metric": "device-resident ensemble slice bits/sec (LSTM -> 41 Indirect -> 33 mixers, forward+update)",
         "value": S * T * args.steps / el, "unit": "bits/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "data": "synthetic",
-        "config": {"streams": S, "bytes_per_stream_per_step": NB,
+        "config": {"streams": S, "bytes_per_stream_per_step": NB, "lstm_cus_per_xcd": args.lstm_cus,
                    "state_bytes_per_stream": lg.bank_bytes + ig.bank_bytes + mg.bank_bytes}}))
 
 

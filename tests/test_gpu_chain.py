@@ -95,6 +95,11 @@ def test_chain_over_several_steps_with_alternating_batches(gpu, oracle):
     LSTM_SLOT, IND_LSTM, MIX_LSTM = 1, 16, 22
     slots = [(8 + 2 * i, 9 + 2 * i) for i in range(K)]
     lg, ig, mg = gpu.LstmGroup(S), gpu.IndirectGroup(models, *tabs, S, slots=slots), gpu.MixerGroup(topo, S)
+    # the LSTM on one half of every XCD's compute units, the other two banks on the other half: their
+    # kernels then run side by side (scripts/bench_pipeline.py) -- and must give the same floats
+    lg.set_cu_mask([0x0000FFFF] * 8)
+    ig.set_cu_mask([0xFFFF0000] * 8)
+    mg.set_cu_mask([0xFFFF0000] * 8)
     lbs = [gpu.LstmBatch(lg, NB) for _ in range(2)]
     ibs = [gpu.IndirectBatch(ig, T) for _ in range(2)]
     mbs = [gpu.Batch(mg, T, outputs=True, mask=True) for _ in range(2)]
@@ -161,6 +166,8 @@ def test_chain_over_several_steps_with_alternating_batches(gpu, oracle):
             fill(k + 1)             # host work and uploads of the next step while this one runs
     check(STEPS - 2)
     check(STEPS - 1)
+    for grp in (lg, ig, mg):
+        grp.set_cu_mask(None)           # back to all compute units
     for s in range(S):
         lm, io, mo = chains[s]
         assert mg.export(s) == (mo.export_long(), mo.export_short()) and ig.export(s) == io.export()
