@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--lstm-cus", type=int, default=16,
                     help="CUs per XCD (of 32) the LSTM kernels get; the mixers and Indirect models get the rest")
+    ap.add_argument("--indirect-all", action="store_true", help="the Indirect models keep all CUs")
     ap.add_argument("--mask-layout", default="xcd", help="xcd: CU i of XCD x is mask bit 32x+i; flat: the first CUs")
     args = ap.parse_args()
     import gmix_amd
@@ -48,7 +49,7 @@ def main():
             lm = [(bits >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
         rest = [(~w) & 0xFFFFFFFF for w in lm]
         lg.set_cu_mask(lm)          # the LSTM on `n` CUs of every XCD ...
-        ig.set_cu_mask(rest)        # ... the Indirect models and the mixers on the others: side by side
+        ig.set_cu_mask(None if args.indirect_all else rest)  # ... the Indirect models and the mixers on the others
         mg.set_cu_mask(rest)
     # two sets of downstream records: the LSTM works on step k+1 while the mixers still read step k's
     lb = gmix_amd.LstmBatch(lg, NB)
