@@ -162,3 +162,10 @@ def test_lstm_entry_points_reject_bad_arguments():
     assert L.gmx_lstm_import(None, 0, None, 0, None, 0) == -1
     assert L.gmx_lstm_copy(None, 0, None, 0) == -1
     assert L.gmx_lstm_memory_usage(None, None) == -1
+    m = (C.c_uint32 * 8)(*([0xFFFF] * 8))
+    assert L.gmx_lstm_set_cu_mask(None, m, 8) == -1
+    assert L.gmx_indirect_set_cu_mask(None, m, 8) == -1
+    assert L.gmx_group_set_cu_mask(None, m, 8) == -1
+    assert L.gmx_lockstep_create(None, None, 0) == -1
+    assert L.gmx_lockstep_predict(None) == -1 and L.gmx_lockstep_learn(None) == -1
+    assert L.gmx_lockstep_learn_predict(None) == -1 and not L.gmx_lockstep_batch(None)
