@@ -1,23 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- mixer bits/s on MI355X, BASELINE.json configs[1]:
-synthetic 256-input 1-layer mixer, random logits, forward + update, 10^8 bits by default.
+"""bench.py -- mixer bits/s on MI355X.
 
-A "step" is one pass of the hot path (Predict + Perceive + Learn for every bit) over one batch
-of synthetic records: S independent streams x T bits, records already resident in HBM
-(generated on the device before the timed region, BASELINE.json "synthetic").  Each stream
-owns a dense 2^16-row x 256-weight gate table (64 MiB), so S streams use S x 64.5 MiB of HBM.
+The headline line is BASELINE.json configs[1]: synthetic 256-input 1-layer mixer, random logits,
+forward + update, 10^8 bits by default.  A "step" is one pass of the hot path (Predict + Perceive +
+Learn for every bit) over one batch of synthetic records: S independent streams x T bits, records
+already resident in HBM (generated on the device before the timed region).  Each stream owns a
+dense 2^16-row x 256-weight gate table (64 MiB), so S streams use S x 64.5 MiB of HBM.
 
   python bench.py [--gpus N --steps K --warmup W] [--streams S --bits T --config single|synth3|stock]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; streams shard across ranks with
-no data-path collective (weak scaling: S streams per GPU); the only communication is the
-barrier and a MAX all-reduce of the elapsed time over RCCL.
+The same JSON line carries, under "also", the other shapes the north_star names, each timed the same
+way (barrier, K steps, max over ranks) with its own roofline and one-core reference figure:
+  synth3       256 inputs x 24/8/1 mixers (configs[2]'s shape), new gate rows every bit
+  stock_held   the reference's own 90 inputs x 24/8/1, gate contexts held through a byte
+  stock_fresh  the same with every gate context new every bit (worst case)
+  stock_S1     ONE stream of the reference's shape: what a single compressor sees
+(--no-also leaves them out; --config X makes X the headline workload for profiling.)
 
-Prints ONE JSON line (rank 0) with the contract's fields plus "roofline" and "cpu_baseline".
+N > 1: one rank per GPU over RCCL.  Under torch.distributed.run the ranks come from the environment;
+started plainly (`python bench.py --gpus N`, WORLD_SIZE unset) this process touches neither torch nor
+HIP and starts torch.distributed.run itself as a child, relaying rank 0's line and the exit code.
+Streams shard across ranks with no data-path collective (weak scaling: S streams per GPU); the only
+communication is the barrier, a MAX all-reduce of the elapsed time and a SUM of the stream counts.
+
+Prints ONE JSON line (rank 0) with the contract's fields plus "roofline", "cpu_baseline", "also".
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -27,16 +38,44 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+WORKLOADS = {
+    # name: (topology, ctx_mode, default streams per GPU, default bits per stream per step, target total bits,
+    #        one-core sample bits, description)
+    "single": ("single", 0, 4096, 512, 100_000_000, 20_000_000,
+               "configs[1]: synthetic 256-input 1-layer mixer (1 mixer, 2^16-row gate table), random logits, forward+update"),
+    "synth3": ("synth3", 0, 1024, 512, 4_000_000, 300_000,
+               "synthetic 256-input 3-layer 24/8/1 bank (2^12-row layer-0 tables), new gate rows every bit, forward+update"),
+    "stock": ("stock", 0, 1024, 256, 4_000_000, 400_000,
+              "stock 24/8/1 topology of Predictor::AddMixers, 90 inputs, synthetic records, forward+update"),
+    "stock_held": ("stock", 2, 1024, 256, 4_000_000, 800_000,
+                   "stock 24/8/1 topology of Predictor::AddMixers, 90 inputs, synthetic records, gate contexts redrawn every 8th bit, forward+update"),
+    "stock_fresh": ("stock", 0, 1024, 256, 2_000_000, 400_000,
+                    "stock 24/8/1 topology of Predictor::AddMixers, 90 inputs, synthetic records, every gate context new every bit, forward+update"),
+    "stock_S1": ("stock", 2, 1, 8192, 32_768, 800_000,
+                 "ONE stream of the stock 24/8/1 topology (90 inputs), gate contexts redrawn every 8th bit, forward+update"),
+}
+ALSO = ("synth3", "stock_held", "stock_fresh", "stock_S1")
 
-def make_topology(name):
+
+def make_topology(kind):
     from gmix_amd import topology
-    if name == "single":
-        return topology.single(256, 1 << 16, 0.005), "configs[1]: synthetic 256-input 1-layer mixer (1 mixer, 2^16-row gate table), random logits, forward+update"
-    if name == "synth3":
-        return topology.synth3(256, table0=1 << 12), "synthetic 256-input 3-layer 24/8/1 bank (2^12-row layer-0 tables), forward+update"
-    if name == "stock":
-        return topology.stock(90), "stock 24/8/1 topology of Predictor::AddMixers, 90 inputs, synthetic records, forward+update"
-    raise SystemExit(f"unknown --config {name}")
+    if kind == "single":
+        return topology.single(256, 1 << 16, 0.005)
+    if kind == "synth3":
+        return topology.synth3(256, table0=1 << 12)
+    if kind == "stock":
+        return topology.stock(90)
+    raise SystemExit(f"unknown topology {kind}")
+
+
+def host_cpu():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
 
 
 def cpu_baseline(topo, sample_bits, ctx_mode=0, ctx_mod=1):
@@ -45,6 +84,7 @@ def cpu_baseline(topo, sample_bits, ctx_mode=0, ctx_mod=1):
     spec = ",".join(f"{l}:{t}:{lr!r}" for l, t, lr in topo.mixers)
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_mixer_bench_fast")
     ncpu = os.cpu_count()
+    cpu = host_cpu()
     if os.path.exists(exe):
         try:
             out = subprocess.run([exe, "--n", str(topo.n_inputs), "--topo", spec, "--bits", str(sample_bits),
@@ -53,9 +93,10 @@ def cpu_baseline(topo, sample_bits, ctx_mode=0, ctx_mod=1):
             r = json.loads(out.strip().splitlines()[-1])
             return {"value": r["bits_per_s"], "unit": "bits/s", "cores": 1, "kind": "reference",
                     "sample": f"{sample_bits} bits of the same synthetic stream through the reference's own "
-                              f"Mixer::Predict+Learn (makefile flags -Ofast -march=native), 1 thread of {ncpu} host cores"}
-        except Exception as e:  # fall through to the port
-            sys.stderr.write(f"[bench] reference baseline failed: {e}\n")
+                              f"Mixer::Predict+Learn (-Ofast -march=x86-64-v3: the makefile's flags with a portable "
+                              f"-march), 1 thread of {ncpu} host cores, {cpu}"}
+        except Exception as e:  # SIGILL on an older host, missing binary ...: say so and use the port
+            sys.stderr.write(f"[bench] reference baseline failed ({e}); timing the C restatement instead\n")
     from oracle import gmxo
     pred, act, ctx, bits = gmxo.synth(topo.n_inputs, topo.n_mixers, sample_bits, ctx_mode=ctx_mode, ctx_mod=ctx_mod)
     b = gmxo.Bank(topo.n_inputs, topo.skip, topo.mixers)
@@ -63,7 +104,161 @@ def cpu_baseline(topo, sample_bits, ctx_mode=0, ctx_mod=1):
     b.run(pred, act, ctx, bits, want_all=False)
     dt = time.perf_counter() - t0
     return {"value": sample_bits / dt, "unit": "bits/s", "cores": 1, "kind": "port",
-            "sample": f"{sample_bits} bits of the same synthetic stream through oracle/gmx_oracle.c, 1 thread of {ncpu} host cores"}
+            "sample": f"{sample_bits} bits of the same synthetic stream through oracle/gmx_oracle.c, 1 thread of "
+                      f"{ncpu} host cores, {cpu}"}
+
+
+def kernel_of(topo, kind, stock_pairs):
+    if topo.n_mixers == 1:
+        return "gmx_single_kernel"
+    if kind == "stock":
+        return "gmx_wide_kernel" if stock_pairs else "gmx_stock_kernel"
+    return "gmx_wide_kernel" if kind == "synth3" else "gmx_bank_kernel"
+
+
+def pmc_traffic(kernel, S, T, ctx_mode, build):
+    """HBM traffic per launch from the committed rocprofv3 PMC summary of the same launch shape (the
+    counters need separate profiled passes, scripts/gpu_profile.sh; they cannot run inside the timed
+    process).  Marked stale when the summary was taken on another build of the library."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+        try:
+            pm = json.load(open(f))
+        except Exception:
+            continue
+        if (pm.get("streams"), pm.get("bits_per_stream")) != (S, T) or kernel not in pm.get("kernel", ""):
+            continue
+        if pm.get("ctx_mode", ctx_mode) != ctx_mode:
+            continue
+        return {"traffic": pm["traffic_bytes_per_launch"], "traffic_source": os.path.relpath(f, ROOT),
+                "traffic_stale": pm.get("build") != build}
+    return {"traffic": None}
+
+
+class Comm:
+    """The three collectives of the bench (RCCL when torch.distributed is up, identity otherwise)."""
+
+    def __init__(self, dist, n_gpus, rank):
+        self.dist, self.n_gpus, self.rank = dist, n_gpus, rank
+
+    def barrier(self):
+        if self.dist is not None:
+            import torch
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+    def max(self, v):
+        from gmix_amd import shard
+        return shard.max_over_ranks(v, self.dist, device="cuda") if self.dist is not None else float(v)
+
+    def sum(self, v):
+        from gmix_amd import shard
+        return shard.sum_over_ranks(v, self.dist, device="cuda") if self.dist is not None else int(v)
+
+
+def run_workload(name, comm, local_rank, streams=None, bits=None, steps=None, warmup=2, ring_n=4,
+                 ctx_mode=None, ctx_mod=1, stock_pairs=False, variant=0, want_cpu=True, cpu_sample_bits=None):
+    """Time K steps of one workload on this rank's GPU; rank 0 gets the result dict."""
+    import gmix_amd
+    kind, mode0, S0, T0, total, sample0, workload = WORKLOADS[name]
+    topo = make_topology(kind)
+    ctx_mode = mode0 if ctx_mode is None else ctx_mode
+    S = streams or S0
+    T = bits or T0
+    g = None
+    while g is None:
+        try:
+            g = gmix_amd.MixerGroup(topo, S, device=local_rank)
+        except gmix_amd.GmxError as e:
+            if e.status != -2 or S <= 64:
+                raise
+            S = max(64, (S * 3 // 4) // 64 * 64)  # dense tables did not fit: fewer streams
+    if steps is None:
+        steps = max(1, -(-total // (S * T)))
+    if variant:
+        import ctypes
+        g.L.gmx_debug_single_variant.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        assert g.L.gmx_debug_single_variant(g.h, variant) == 0
+    if stock_pairs:
+        import ctypes
+        g.L.gmx_debug_stock_pairs.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        assert g.L.gmx_debug_stock_pairs(g.h, 1) == 0
+    ring = [gmix_amd.Batch(g, T, outputs=False, mask=False) for _ in range(ring_n)]
+    for i, b in enumerate(ring):
+        b.fill_synthetic(T, seed=0x9E3779B97F4A7C15 + 1000003 * (comm.rank * ring_n + i), restart=True,
+                         ctx_mode=ctx_mode, ctx_mod=ctx_mod)
+    g.sync()
+    for k in range(warmup):
+        g.run(ring[k % len(ring)], T, learn=True)
+    g.sync()
+    comm.barrier()
+    # K launches queued without a host synchronisation in between (the host prepares launch k+1
+    # while launch k runs); HIP events on the group's stream bracket them for the roofline
+    t0 = time.perf_counter()
+    g.timer_start()
+    for k in range(steps):
+        g.run(ring[k % len(ring)], T, learn=True)
+    gpu_ms = g.timer_stop()
+    g.sync()
+    comm.barrier()
+    elapsed = comm.max(time.perf_counter() - t0)
+    S_all = comm.sum(S)  # a rank with less free HBM runs fewer streams
+    bank_bytes = g.bank_bytes
+    build = g.L.gmx_build_info().decode()
+    for b in ring:
+        b.close()
+    g.close()
+    if comm.rank != 0:
+        return None
+    avg_ms = gpu_ms / steps
+    bits_per_step = S_all * T
+    # rows move when a gate context changes: every bit (ctx-mode 0/1) or every 8th bit (2/3)
+    row_bytes = 8 * sum(topo.weight_sizes())
+    hold = 8 if ctx_mode >= 2 else 1
+    bytes_per_bit = row_bytes // hold + topo.bytes_per_bit() - row_bytes
+    bytes_per_launch = bytes_per_bit * S * T
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    kernel = kernel_of(topo, kind, stock_pairs)
+    out = {
+        "value": bits_per_step * steps / elapsed, "unit": "bits/s", "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "config": {"workload": workload + (", gate contexts redrawn every 8th bit"
+                                           if hold == 8 and "8th" not in workload else ""),
+                   "n_inputs": topo.n_inputs, "mixers": f"{topo.l0}/{topo.l1}/{1 if topo.has_final else 0}",
+                   "streams_per_gpu": S, "bits_per_stream_per_step": T, "bits_per_step": bits_per_step,
+                   "total_bits": bits_per_step * steps, "bank_bytes_per_stream": bank_bytes,
+                   "parallelism": f"streams sharded over {comm.n_gpus} GPU(s), no collective on the data path"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel, "kernel_ms_avg": avg_ms,
+                     "algorithmic_bytes_per_bit": bytes_per_bit, "bytes_per_launch": bytes_per_launch,
+                     "build": build},
+    }
+    try:
+        out["roofline"].update(pmc_traffic(kernel, S, T, ctx_mode, build))
+    except Exception as e:
+        sys.stderr.write(f"[bench] no PMC summary: {e}\n")
+    if want_cpu and comm.n_gpus == 1:
+        out["cpu_baseline"] = cpu_baseline(topo, cpu_sample_bits or sample0, ctx_mode, ctx_mod)
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: this parent has touched neither torch
+    nor HIP; it starts torch.distributed.run as a CHILD process (never an exec) and hands on its
+    output and exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -73,144 +268,94 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=None,
                     help="independent streams per GPU (each owns a dense 64.5 MiB gate table: 3072 = 194 GiB of HBM)")
-    ap.add_argument("--bits", type=int, default=512, help="bits per stream per step")
-    ap.add_argument("--config", default="single")
+    ap.add_argument("--bits", type=int, default=None, help="bits per stream per step")
+    ap.add_argument("--config", default="single", choices=sorted(WORKLOADS))
     ap.add_argument("--ring", type=int, default=4, help="distinct record batches cycled through")
     ap.add_argument("--variant", type=int, default=0,
                     help="tuning: lanes per stream of the single-mixer kernel (0 = library default)")
-    ap.add_argument("--ctx-mode", type=int, default=0,
+    ap.add_argument("--ctx-mode", type=int, default=None,
                     help="0: fresh 32-bit gate contexts every bit (BASELINE configs[1]); 2/3: contexts held "
                          "for 8 bits like byte-boundary contexts (oracle/gmx_synth.h)")
     ap.add_argument("--ctx-mod", type=int, default=1)
     ap.add_argument("--stock-pairs", action="store_true",
-                    help="--config stock: the lane-pair kernel (gmx_wide.hip) instead of the generated streams")
+                    help="--config stock*: the lane-pair kernel (gmx_wide.hip) instead of the generated streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-bits", type=int, default=20_000_000,
-                    help="bits of the same stream for the one-core reference (about 15 s of CPU work)")
+    ap.add_argument("--no-also", action="store_true", help="only the headline workload")
+    ap.add_argument("--rehearse-cpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-sample-bits", type=int, default=None,
+                    help="bits of the same stream for the one-core reference (default: about 5-15 s of CPU work)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("GMX_BENCH_FORCE_DIST")):
+        sys.exit(spawn_ranks(args.gpus))  # GMX_BENCH_FORCE_DIST rehearses the N > 1 path on one GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.stderr.write(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: refusing to report a figure for a "
+                         f"GPU count that is not the one that ran\n")
+        sys.exit(2)
     dist = None
-    if world > 1 or os.environ.get("GMX_BENCH_FORCE_DIST"):  # the env var rehearses the N>1 path on one GPU
+    if args.rehearse_cpu:
+        # the launch plumbing alone, on CPU: gloo, no GPU work, no figure (tests/test_bench_spawn.py)
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        from gmix_amd import shard
+        total = shard.sum_over_ranks(1, dist)
+        slowest = shard.max_over_ranks(float(rank), dist)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"rehearsal": True, "n_gpus": world, "ranks_counted": total, "max_rank": slowest,
+                              "value": None}), flush=True)
+        dist.destroy_process_group()
+        return
+    if world > 1 or os.environ.get("GMX_BENCH_FORCE_DIST"):
         # torch first: libgmxmix.so then binds to the HIP runtime torch has already loaded
         # (same soname), so RCCL and the mixer kernels share one runtime in this process.
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if local_rank >= torch.cuda.device_count():
+            sys.stderr.write(f"[bench] rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)\n")
+            sys.exit(3)
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        sys.stderr.write(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE\n")
-    n_gpus = world
+    comm = Comm(dist, world, rank)
 
-    import gmix_amd
-    topo, workload = make_topology(args.config)
-    if args.streams is None:  # what fills the chip for the shape: one wave per SIMD (4 one-mixer streams per wave)
-        args.streams = 4096 if args.config == "single" else 1024
-    S, T = args.streams, args.bits
-    steps = args.steps if args.steps is not None else max(1, -(-100_000_000 // (S * T)))  # 10^8 bits
-
-    g = None
-    while g is None:
-        try:
-            g = gmix_amd.MixerGroup(topo, S, device=local_rank)
-        except gmix_amd.GmxError as e:
-            if e.status != -2 or S <= 64:
-                raise
-            S = max(64, (S * 3 // 4) // 64 * 64)  # dense tables did not fit: fewer streams
-    if args.variant:
-        import ctypes
-        g.L.gmx_debug_single_variant.argtypes = [ctypes.c_void_p, ctypes.c_int]
-        assert g.L.gmx_debug_single_variant(g.h, args.variant) == 0
-    if args.stock_pairs:
-        import ctypes
-        g.L.gmx_debug_stock_pairs.argtypes = [ctypes.c_void_p, ctypes.c_int]
-        assert g.L.gmx_debug_stock_pairs(g.h, 1) == 0
-    ring = [gmix_amd.Batch(g, T, outputs=False, mask=False) for _ in range(args.ring)]
-    for i, b in enumerate(ring):
-        b.fill_synthetic(T, seed=0x9E3779B97F4A7C15 + 1000003 * (rank * args.ring + i), restart=True,
-                         ctx_mode=args.ctx_mode, ctx_mod=args.ctx_mod)
-    g.sync()
-
-    for k in range(args.warmup):
-        g.run(ring[k % len(ring)], T, learn=True)
-    g.sync()
-    if dist is not None:
-        import torch
-        dist.barrier()
-        torch.cuda.synchronize()
-    # K launches queued without a host synchronisation in between (the host prepares launch k+1
-    # while launch k runs); HIP events on the group's stream bracket them for the roofline
-    t0 = time.perf_counter()
-    g.timer_start()
-    for k in range(steps):
-        g.run(ring[k % len(ring)], T, learn=True)
-    gpu_ms = g.timer_stop()
-    g.sync()
-    if dist is not None:
-        import torch
-        torch.cuda.synchronize()
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    S_all = S * n_gpus
-    if dist is not None:
-        from gmix_amd import shard
-        elapsed = shard.max_over_ranks(elapsed, dist, device="cuda")
-        S_all = shard.sum_over_ranks(S, dist, device="cuda")  # a rank with less free HBM runs fewer streams
-    kernel_ms = [gpu_ms / steps]
-
+    head = run_workload(args.config, comm, local_rank, streams=args.streams, bits=args.bits, steps=args.steps,
+                        warmup=args.warmup, ring_n=args.ring, ctx_mode=args.ctx_mode, ctx_mod=args.ctx_mod,
+                        stock_pairs=args.stock_pairs, variant=args.variant, want_cpu=not args.no_cpu_baseline,
+                        cpu_sample_bits=args.cpu_sample_bits)
+    also = {}
+    if not args.no_also:
+        for name in ALSO:
+            if name == args.config:
+                continue
+            try:
+                r = run_workload(name, comm, local_rank, warmup=1, ring_n=2,
+                                 want_cpu=not args.no_cpu_baseline and name != "stock_S1")
+            except Exception as e:  # a sub-result must never cost the headline line
+                if dist is not None:
+                    raise  # ... except across ranks, where a lone failure would leave the others in a barrier
+                r = {"error": f"{type(e).__name__}: {e}"}
+            if rank == 0:
+                also[name] = r
+        if rank == 0 and "cpu_baseline" in also.get("stock_held", {}) and "error" not in also.get("stock_S1", {"error": 1}):
+            # one stream of the same workload: the one-core reference figure is the same measurement
+            also["stock_S1"]["cpu_baseline"] = dict(also["stock_held"]["cpu_baseline"])
     if rank == 0:
-        bits_per_step = S_all * T
-        value = bits_per_step * steps / elapsed
-        avg_ms = sum(kernel_ms) / len(kernel_ms)
-        # rows move when a gate context changes: every bit (ctx-mode 0/1) or every 8th bit (2/3)
-        row_bytes = 8 * sum(topo.weight_sizes())
-        hold = 8 if args.ctx_mode >= 2 else 1
-        bytes_per_bit = row_bytes // hold + topo.bytes_per_bit() - row_bytes
-        bytes_per_launch = bytes_per_bit * S * T
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        out = {
-            "metric": "mixer bits/sec (synthetic 256-input mixer streams, forward+update)",
-            "value": value, "unit": "bits/s", "n_gpus": n_gpus, "steps": steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload + ("" if hold == 1 else ", gate contexts redrawn every 8th bit"),
-                       "n_inputs": topo.n_inputs,
-                       "mixers": f"{topo.l0}/{topo.l1}/{1 if topo.has_final else 0}",
-                       "streams_per_gpu": S, "bits_per_stream_per_step": T,
-                       "bits_per_step": bits_per_step, "total_bits": bits_per_step * steps,
-                       "bank_bytes_per_stream": g.bank_bytes, "parallelism": f"streams sharded over {n_gpus} GPU(s), no collective on the data path"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": ("gmx_single_kernel" if topo.n_mixers == 1 else
-                                    ("gmx_wide_kernel" if args.stock_pairs else "gmx_stock_kernel") if args.config == "stock" else ("gmx_wide_kernel" if args.config == "synth3" else "gmx_bank_kernel")),
-                         "kernel_ms_avg": avg_ms,
-                         "algorithmic_bytes_per_bit": bytes_per_bit,
-                         "bytes_per_launch": bytes_per_launch},
-        }
-        # HBM traffic per launch comes from rocprofv3 PMC passes of this same command (they
-        # cannot run inside the timed process); the committed summary is quoted when it was
-        # taken on the same launch shape, otherwise the field stays null.
-        try:
-            import glob
-            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
-                pm = json.load(open(f))
-                if (pm.get("streams"), pm.get("bits_per_stream")) == (S, T) and \
-                        out["roofline"]["kernel"] in pm.get("kernel", ""):
-                    out["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = os.path.relpath(f, ROOT)
-                    break
-        except Exception as e:
-            sys.stderr.write(f"[bench] no PMC summary: {e}\n")
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            sample = args.cpu_sample_bits if topo.n_mixers == 1 else min(args.cpu_sample_bits, 1_500_000)
-            out["cpu_baseline"] = cpu_baseline(topo, sample, args.ctx_mode, args.ctx_mod)
+        out = {"metric": "mixer bits/sec (synthetic 256-input mixer streams, forward+update)",
+               "value": head["value"], "unit": "bits/s", "n_gpus": world, "steps": head["steps"],
+               "warmup": head["warmup"], "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": head["config"], "roofline": head["roofline"]}
+        if "cpu_baseline" in head:
+            out["cpu_baseline"] = head["cpu_baseline"]
+        if also:
+            out["also"] = also
         print(json.dumps(out), flush=True)
-    for b in ring:
-        b.close()
-    g.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Turn the CSVs of scripts/gpu_profile.sh into profiles/rNN_<tag>_* files.
 
-  python scripts/pmc_summary.py <tag> <round> <kernel-name-prefix> <streams> <bits> <alg-bytes-per-bit> "<command>"
+  python scripts/pmc_summary.py <tag> <round> <kernel-name-prefix> <streams> <bits> <alg-bytes-per-bit> "<command>" [ctx_mode]
+
+The library build the passes ran on (gmx_build_info(), printed by bench.py in roofline.build) is read from
+the stats pass's JSON line; bench.py marks a quoted figure stale when it no longer matches.
 
 FETCH_SIZE is doubled (gfx950 reports half the bytes of 16-B-per-lane reads, MI355X_MICROARCH.md);
 WRITE_SIZE is taken as is; both are in KiB per dispatch."""
@@ -13,6 +16,7 @@ import shutil
 import sys
 
 tag, rnd, kprefix, S, T, apb, cmd = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
+ctx_mode = int(sys.argv[8]) if len(sys.argv) > 8 else 0
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -46,8 +50,15 @@ for r in csv.DictReader(open(stats)):
     if kprefix in r["Name"]:
         kname, kavg = r["Name"], float(r["AverageNs"]) * 1e-6
         break
+build = None
+try:
+    for line in open(os.path.join(src, "stats.log")):
+        if line.startswith("{"):
+            build = json.loads(line)["roofline"].get("build")
+except Exception:
+    pass
 out = {
-    "round": rnd, "command": cmd, "kernel": kname, "kernel_ms_avg_rocprof": kavg,
+    "round": rnd, "build": build, "ctx_mode": ctx_mode, "command": cmd, "kernel": kname, "kernel_ms_avg_rocprof": kavg,
     "streams": S, "bits_per_stream": T, "dispatches_counted": [nf, nw],
     "FETCH_SIZE_kb_avg": f_kb, "WRITE_SIZE_kb_avg": w_kb,
     "fetch_bytes_corrected": f_kb * 1024 * 2, "write_bytes": w_kb * 1024,
