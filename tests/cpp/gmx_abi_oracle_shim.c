@@ -1,0 +1,119 @@
+/* gmx_abi_oracle_shim.c -- TEST INFRASTRUCTURE, CPU only.  NOT a fallback and never shipped:
+ * the product library has no CPU path (GMX_ERR_NO_DEVICE).  This file answers the eight C-ABI
+ * entry points gmx_model_adapter.h calls with the oracle's restatement, so that the adapter's
+ * HOST logic (registration, staging through LongTermMemory::mixers, checkpoint order, Copy) can
+ * be run against the real reference in the build container, where there is no GPU
+ * (tests/test_dropin_cpu.py).  The GPU proof is tests/test_gpu_dropin.py, against libgmxmix.so. */
+#include "../../oracle/gmx_oracle.c"
+
+#include "../../include/gmxmix.h"
+
+struct gmx_group {
+  gmxo_bank* b;
+};
+
+const char* gmx_strerror(int s) { return s == GMX_OK ? "ok" : s == GMX_ERR_FORMAT ? "malformed checkpoint" : "error"; }
+const char* gmx_last_error(void) { return ""; }
+
+int gmx_group_create(gmx_group** out, const gmx_topology* t, int n_streams, int device) {
+  (void)device;
+  if (!out || !t || n_streams != 1) return GMX_ERR_INVALID;
+  int layer[64];
+  uint32_t table[64];
+  float lr[64];
+  int skip[8];
+  for (int j = 0; j < t->n_mixers; ++j) {
+    layer[j] = t->mixers[j].layer;
+    table[j] = t->mixers[j].table_size;
+    lr[j] = t->mixers[j].learning_rate;
+  }
+  for (int i = 0; i < t->n_skip; ++i) skip[i] = t->skip_index[i];
+  gmx_group* g = (gmx_group*)calloc(1, sizeof(*g));
+  g->b = gmxo_create(t->n_inputs, t->n_skip, skip, t->n_mixers, layer, table, lr);
+  *out = g;
+  return GMX_OK;
+}
+
+void gmx_group_destroy(gmx_group* g) {
+  if (!g) return;
+  gmxo_destroy(g->b);
+  free(g);
+}
+
+int gmx_bank_forward(gmx_group* g, int stream, const float* predictions, const int32_t* active, int n_active,
+                     const uint32_t* contexts, float* p_final, float* out_all) {
+  if (!g || stream != 0 || n_active < 0) return GMX_ERR_INVALID;
+  *p_final = gmxo_predict(g->b, predictions, active, n_active, contexts, out_all);
+  return GMX_OK;
+}
+
+int gmx_bank_learn(gmx_group* g, int stream, int bit) {
+  if (!g || stream != 0) return GMX_ERR_INVALID;
+  gmxo_learn(g->b, bit);
+  return GMX_OK;
+}
+
+int gmx_bank_export(gmx_group* g, int stream, void* long_buf, size_t* long_bytes, void* short_buf,
+                    size_t* short_bytes) {
+  if (!g || stream != 0) return GMX_ERR_INVALID;
+  size_t nl = gmxo_export_long(g->b, 0, 0), ns = gmxo_export_short(g->b, 0, 0);
+  if (long_buf) gmxo_export_long(g->b, long_buf, nl);
+  if (short_buf) gmxo_export_short(g->b, short_buf, ns);
+  *long_bytes = nl;
+  *short_bytes = ns;
+  return GMX_OK;
+}
+
+/* Mixer::ReadFromDisk x M + the mixer section of LongTermMemory::ReadFromDisk (mixer.cpp:184-188,
+ * long-term-memory.cpp:134-149) */
+int gmx_bank_import(gmx_group* g, int stream, const void* long_buf, size_t long_bytes, const void* short_buf,
+                    size_t short_bytes) {
+  if (!g || stream != 0 || short_bytes != (size_t)g->b->m * 24) return GMX_ERR_FORMAT;
+  const uint8_t* p = (const uint8_t*)long_buf;
+  const uint8_t* end = p + long_bytes;
+  const uint64_t* sh = (const uint64_t*)short_buf;
+  for (int j = 0; j < g->b->m; ++j) {
+    gmxo_mixer* x = &g->b->mx[j];
+    memset(x->w, 0, sizeof(float) * (size_t)x->table_size * x->weight_size);
+    memset(x->row_steps, 0, sizeof(uint64_t) * x->table_size);
+    x->steps = sh[3 * j];
+    x->max_steps = sh[3 * j + 1];
+    x->contexts_seen = sh[3 * j + 2];
+    if (end - p < 8) return GMX_ERR_FORMAT;
+    uint32_t cnt, in;
+    memcpy(&cnt, p, 4);
+    memcpy(&in, p + 4, 4);
+    p += 8;
+    if (cnt && in != (uint32_t)x->weight_size) return GMX_ERR_FORMAT;
+    for (uint32_t i = 0; i < cnt; ++i) {
+      if ((size_t)(end - p) < 12 + 4 * (size_t)in) return GMX_ERR_FORMAT;
+      uint32_t r;
+      memcpy(&r, p, 4);
+      if (r >= x->table_size) return GMX_ERR_FORMAT;
+      memcpy(&x->row_steps[r], p + 4, 8);
+      memcpy(x->w + (size_t)r * x->weight_size, p + 12, 4 * (size_t)in);
+      p += 12 + 4 * (size_t)in;
+    }
+  }
+  return p == end ? GMX_OK : GMX_ERR_FORMAT;
+}
+
+int gmx_bank_copy(gmx_group* dst, int ds, gmx_group* src, int ss) {
+  if (!dst || !src || ds || ss || dst->b->m != src->b->m) return GMX_ERR_INVALID;
+  for (int j = 0; j < dst->b->m; ++j) {
+    gmxo_mixer *a = &dst->b->mx[j], *b = &src->b->mx[j];
+    if (a->table_size != b->table_size || a->weight_size != b->weight_size) return GMX_ERR_INVALID;
+    memcpy(a->w, b->w, sizeof(float) * (size_t)a->table_size * a->weight_size);
+    memcpy(a->row_steps, b->row_steps, sizeof(uint64_t) * a->table_size);
+    a->steps = b->steps;
+    a->max_steps = b->max_steps;
+    a->contexts_seen = b->contexts_seen;
+  }
+  return GMX_OK;
+}
+
+int gmx_bank_memory_usage(gmx_group* g, int stream, int mixer, uint64_t* bytes) {
+  if (!g || stream != 0 || mixer < 0 || mixer >= g->b->m) return GMX_ERR_INVALID;
+  *bytes = gmxo_memory_usage(g->b, mixer);
+  return GMX_OK;
+}
