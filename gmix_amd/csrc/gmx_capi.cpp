@@ -172,7 +172,8 @@ struct gmx_group {
     uint32_t* idx_dev = nullptr;
     float* host = nullptr;         // pinned
     uint32_t* idx_host = nullptr;
-    size_t cap = 0;                // floats
+    size_t cap = 0;                // floats of dev / host
+    size_t idx_cap = 0;            // entries of idx_dev / idx_host (one per stream of a launch)
     hipEvent_t done = nullptr;     // recorded behind the kernel that read this slot
     hipEvent_t ready = nullptr;    // recorded behind the upload on copy_stream
     bool busy = false;
@@ -605,23 +606,28 @@ static int prepare_decay(gmx_group* g, int s0, int ns, uint64_t T, int learn, gm
     HIPCHK(hipEventSynchronize(d.done));
     d.busy = false;
   }
-  const size_t need = (size_t)uniq.size() * T + (size_t)ns;
+  const size_t need = (size_t)uniq.size() * T;
   if (need > d.cap) {
     if (d.dev) (void)hipFree(d.dev);
-    if (d.idx_dev) (void)hipFree(d.idx_dev);
     if (d.host) (void)hipHostFree(d.host);
-    if (d.idx_host) (void)hipHostFree(d.idx_host);
     d.dev = nullptr;
-    d.idx_dev = nullptr;
     d.host = nullptr;
-    d.idx_host = nullptr;
     d.cap = 0;
     size_t cap = need + need / 2 + 1024;
     HIPCHK(hipMalloc((void**)&d.dev, cap * sizeof(float)));
-    HIPCHK(hipMalloc((void**)&d.idx_dev, cap * sizeof(uint32_t)));
     HIPCHK(hipHostMalloc((void**)&d.host, cap * sizeof(float), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&d.idx_host, cap * sizeof(uint32_t), hipHostMallocDefault));
     d.cap = cap;
+  }
+  if ((size_t)ns > d.idx_cap) {  // one row index per stream of the launch
+    if (d.idx_dev) (void)hipFree(d.idx_dev);
+    if (d.idx_host) (void)hipHostFree(d.idx_host);
+    d.idx_dev = nullptr;
+    d.idx_host = nullptr;
+    d.idx_cap = 0;
+    const size_t icap = (size_t)ns + 64;
+    HIPCHK(hipMalloc((void**)&d.idx_dev, icap * sizeof(uint32_t)));
+    HIPCHK(hipHostMalloc((void**)&d.idx_host, icap * sizeof(uint32_t), hipHostMallocDefault));
+    d.idx_cap = icap;
   }
   if (!d.done) {
     HIPCHK(hipEventCreateWithFlags(&d.done, hipEventDisableTiming));
@@ -631,7 +637,9 @@ static int prepare_decay(gmx_group* g, int s0, int ns, uint64_t T, int learn, gm
   // Streams at the same bit count share a row; with many different counts the device makes the
   // table (see gmx_decay_kernel), else the host's libm loop is shorter than the detour.
   bool on_device = false;
-  if (learn && uniq.size() > 1 && uniq.size() * T >= kDecayDeviceMin && !g->decay_on_host) {
+  // (the device's list of unsettled entries holds 32-bit flat indices: larger tables take the host loop)
+  if (learn && uniq.size() > 1 && uniq.size() * T >= kDecayDeviceMin && uniq.size() * T < (1ull << 32) &&
+      !g->decay_on_host) {
     const int rcd = decay_table_on_device(g, d, uniq, T);
     if (rcd != GMX_OK && rcd != GMX_ERR_STATE) return rcd;
     on_device = rcd == GMX_OK;

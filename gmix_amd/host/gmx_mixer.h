@@ -131,6 +131,8 @@ class MixerBank {
     t.skip_index = skip.data();
     t.n_mixers = (int32_t)descs_.size();
     t.mixers = descs_.data();
+    n_inputs_ = stm.num_predictions;
+    n_skip_ = skip.size();
     status_ = gmx_group_create(&group_, &t, 1, device_);
     outputs_.assign(descs_.size(), 0.f);
     contexts_.assign(descs_.size(), 0u);
@@ -203,6 +205,8 @@ class MixerBank {
   std::vector<char> short_cache_;
   std::vector<char> short_in_;
   float last_p_ = 0.5f;
+  int n_inputs_ = 0;
+  size_t n_skip_ = 0;
 };
 
 class Mixer {
@@ -283,14 +287,30 @@ inline void MixerBank::ReadFromDisk(std::ifstream* s) {
   // Parse the section to find its length (long-term-memory.cpp:134-149), then import it with
   // the 3 x u64 per mixer that Mixer::ReadFromDisk collected from the .short file.
   std::vector<char> buf;
+  int k0 = 0, k1 = 0, l0 = 0, l1 = 0;
+  for (const gmx_mixer_desc& d : descs_) (d.layer == 0 ? l0 : l1) += d.layer < 2;
   for (size_t j = 0; j < descs_.size(); ++j) {
-    uint32_t hdr[2];
+    // a header is trusted only as far as the topology allows: at most table_size rows, each of exactly
+    // this mixer's weight_size (mixer.cpp:17-26) -- a truncated or corrupt file is refused, not allocated for
+    uint32_t hdr[2] = {0, 0};
     s->read(reinterpret_cast<char*>(hdr), 8);
+    const gmx_mixer_desc& d = descs_[j];
+    const int n_skip = (int)n_skip_;
+    const uint32_t wsize = d.layer == 0 ? (uint32_t)(n_inputs_ + k0++)
+                           : d.layer == 1 ? (uint32_t)(l0 + k1++ + n_skip) : (uint32_t)(l0 + l1 + n_skip);
+    if (!s->good() || hdr[0] > d.table_size || (hdr[0] > 0 && hdr[1] != wsize)) {
+      Note(GMX_ERR_FORMAT);
+      return;
+    }
     buf.insert(buf.end(), reinterpret_cast<char*>(hdr), reinterpret_cast<char*>(hdr) + 8);
     size_t body = (size_t)hdr[0] * (12 + 4 * (size_t)hdr[1]);
     size_t at = buf.size();
     buf.resize(at + body);
     s->read(buf.data() + at, body);
+    if ((size_t)s->gcount() != body) {
+      Note(GMX_ERR_FORMAT);
+      return;
+    }
   }
   Note(gmx_bank_import(group_, 0, buf.data(), buf.size(), short_in_.data(), short_in_.size()));
 }

@@ -1,5 +1,5 @@
-"""BASELINE.json configs[1] at the bench's full size (3072 streams x 512 bits, 194 GiB of gate
-tables) through properties that do not need the oracle to run 1.5 M bits: a launch split in two
+"""BASELINE.json configs[1] at the bench's full size (4096 streams x 512 bits, 258 GiB of gate
+tables) and the 256-input 24/8/1 bank at ITS bench size (1024 streams x 512 bits) through properties that do not need the oracle to run 1.5 M bits: a launch split in two
 gives the same floats and the same banks; sampled streams equal the oracle run on the same seed;
 streams do not leak into each other."""
 import numpy as np
@@ -9,7 +9,7 @@ from gmix_amd import topology
 
 pytestmark = pytest.mark.gpu
 
-S, T = 3072, 512
+S, T = 4096, 512   # bench.py's defaults for --config single
 GOLD = 0x9E3779B97F4A7C15
 SEED = 0x1234567
 
@@ -22,10 +22,24 @@ def test_full_size_run_is_split_invariant_and_sampled_streams_match_the_oracle(g
     topo = topology.single(256, 1 << 16, 0.005)
     try:
         g = gpu.MixerGroup(topo, S)
-    except gpu.GmxError as e:  # a box with less free HBM than 194 GiB cannot host this case
+    except gpu.GmxError as e:  # a box with less free HBM than 258 GiB cannot host this case
         pytest.skip(f"cannot allocate {S} banks: {e}")
     b = gpu.Batch(g, T, outputs=False, mask=False)
     samples = [0, 1, 777, 2048, S - 1]
+    _split_invariance_and_samples(gpu, oracle, topo, g, b, S, samples)
+
+
+def test_wide_bank_at_bench_size(gpu, oracle):
+    """gmx_wide_kernel at bench.py's synth3 shape: 256 inputs x 24/8/1, 2^12-row layer-0 tables,
+    1024 streams x 512 bits, new gate rows every bit."""
+    topo = topology.synth3(256, table0=1 << 12)
+    Sw = 1024
+    g = gpu.MixerGroup(topo, Sw)
+    b = gpu.Batch(g, T, outputs=False, mask=False)
+    _split_invariance_and_samples(gpu, oracle, topo, g, b, Sw, [0, 1, 500, Sw - 1])
+
+
+def _split_invariance_and_samples(gpu, oracle, topo, g, b, S, samples):
 
     def run(splits):
         g.reset()
@@ -58,7 +72,7 @@ def test_full_size_run_is_split_invariant_and_sampled_streams_match_the_oracle(g
     assert np.isfinite(p1).all() and p1.min() >= np.float32(1e-4) and p1.max() <= np.float32(1) - np.float32(1e-4)
     # sampled streams against the oracle, from the seed alone
     for s in samples:
-        pred, act, ctx, bits = oracle.synth(256, 1, T, seed=(SEED + s * GOLD) % (1 << 64))
+        pred, act, ctx, bits = oracle.synth(256, topo.n_mixers, T, seed=(SEED + s * GOLD) % (1 << 64))
         ob = oracle.Bank(256, topo.skip, topo.mixers)
         p_ref, _ = ob.run(pred, act, ctx, bits)
         assert np.array_equal(u32(p1[s]), u32(p_ref)), s

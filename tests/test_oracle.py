@@ -1,6 +1,8 @@
 """The oracle (oracle/gmx_oracle.c) against golden vectors recorded from the REFERENCE's own
 Mixer / Predictor in the build container (tests/golden/make_golden.py).  Integer compare of
 float bit patterns: tolerance 0."""
+import os
+
 import numpy as np
 import pytest
 
@@ -63,6 +65,28 @@ def test_oracle_matches_reference_long(oracle, name):
         assert meta["h32"] == 0xb864caa7 and abs(meta["acc"] - 18.811666) < 1e-6
     if name == "a3_synth3_n90":
         assert meta["h32"] == 0xf003db20 and abs(meta["acc"] + 20.275474) < 1e-6
+
+
+@pytest.mark.slow
+def test_a3_single_mixer_known_answer(oracle):
+    """SURVEY.md Appendix A.3's single-mixer row (acc -357.038172, hash 957fee36): reproduced once the
+    probe's extra context draw per bit is made (tests/helpers/a3_single.c); the documented recipe
+    without it gives 679de36f, the value of the a3_single256 fixture."""
+    import ctypes
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(here, "helpers", "liba3single.so")
+    odir = os.path.join(os.path.dirname(here), "oracle")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", os.path.join(here, "helpers", "a3_single.c"), "-o", so,
+                           "-L" + odir, "-lgmxoracle", "-Wl,-rpath," + odir])
+    L = ctypes.CDLL(so)
+    L.a3_single.restype = ctypes.c_uint32
+    L.a3_single.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    acc = ctypes.c_double()
+    assert L.a3_single(2_000_000, 1, ctypes.byref(acc)) == 0x957fee36 and abs(acc.value + 357.038172) < 1e-6
+    assert L.a3_single(2_000_000, 0, ctypes.byref(acc)) == 0x679de36f
+    meta, _ = goldenlib.load("a3_single256")
+    assert meta["h32"] == 0x679de36f
 
 
 def test_oracle_matches_reference_predictor_trace(oracle):
