@@ -15,7 +15,9 @@ compiler-generated instruction touches the reserved ranges):
   v44..v47                       temporaries of the streams
   X(j)  = v[48+j],  j = 0..91    the bit's inputs (broadcast-read from LDS)
   W(j)  = v[140+j], j = 0..115   the lane's resident row (lane m = mixer m)
-  WN(j) = a[140+j]               the prefetched row (global loads land in AGPRs)
+  a[140..255]                    the row prefetched lane-private (the 9 quads of a layer-1 / final lane always;
+                                 all 29 quads of a layer-0 lane in launches that do not stage rows through LDS)
+  a[44..139]                     24 quads on their way from the write-back image to the stores
   O0(i) = s[64+i],  i = 0..23    layer-0 outputs;  O1(i) = s[88+i], i = 0..7  layer-1 outputs
 
 Hazards honoured by construction (gfx940/gfx950; the spacing hipcc itself keeps):
@@ -29,7 +31,7 @@ N, L0, L1, M = 90, 24, 8, 33
 NQX = (N + 3) // 4   # 23 quads of inputs
 NQW = 29             # quads of a layer-0 row (113 weights)
 NQA = 9              # quads of a layer-1 / final row that hold weights (33 of the 64 floats stored)
-RESERVED = {"v": (44, 255), "a": (140, 255), "s": (64, 95)}
+RESERVED = {"v": (44, 255), "a": (44, 255), "s": (64, 95)}
 
 
 def W(j):
@@ -61,7 +63,18 @@ def A4(q):
     return f"a[{AB + 4 * q}:{AB + 4 * q + 3}]"
 
 
+WIDE_PREFIXES = ("v_pk_", "v_readlane", "ds_", "global_", "v_accvgpr")
+
+
 def emit(name, lines):
+    if os.environ.get("GMX_STK_ALIGN8") and name in ("GMX_STK_FORWARD", "GMX_STK_UPDATE"):
+        # experiment: every 8-byte instruction on an 8-byte boundary (the assembler pads with s_nop)
+        out = []
+        for l in lines:
+            if l.startswith(WIDE_PREFIXES):
+                out.append(".p2align 3")
+            out.append(l)
+        lines = out
     body = "".join(f'  "{l}\\n\\t" \\\n' for l in lines)
     return f"#define {name} \\\n{body}  \"\"\n\n"
 
@@ -71,6 +84,8 @@ def under_mask(body):
 
 
 def loads(first, last):
+    """lane-private row pieces HBM -> AGPRs (the small rows of the layer-1 / final lanes: 9 pieces
+    of 16 bytes in at most 9 lanes -- too little to be worth staging)"""
     return under_mask([f"global_load_dwordx4 {A4(q)}, %[p], off offset:{16 * q}" for q in range(first, last)])
 
 
@@ -80,6 +95,70 @@ def stores(first, last):
 
 def adopt(first, last):
     return under_mask([f"v_accvgpr_read_b32 {W(j)}, a{AB + j}" for j in range(4 * first, 4 * last)])
+
+
+SP = 64        # s64..s71: four rotating SGPR pairs for row addresses (O0/O1 are dead outside forward..update)
+STG = 44       # a44..a139: 24 quads, the write-back's way from the image to the stores
+PITCH = 528    # bytes between rows of a staging image: 33 quads, odd, so transposed accesses do not conflict
+
+
+def _row_addr(r, lo, hi):
+    p = SP + 2 * (r % 4)
+    return [f"v_readlane_b32 s{p}, {lo}, {r}", f"v_readlane_b32 s{p + 1}, {hi}, {r}"]
+
+
+def fetch_l0():
+    """Layer-0 rows of the mixers in %[nm], HBM -> staging image, one coalesced LDS-DMA per row (32
+    lanes x 16 contiguous bytes) instead of 29 lane-private 16-byte loads that touch 24 different
+    lines each.  The row address lives in lane r (%[plo]/%[phi]) and is made scalar two rows ahead of
+    its use (v_readlane -> VMEM address: 5 wait states); an unchanged row issues with exec = 0."""
+    l = ["s_mov_b64 %[sv], exec", "s_mov_b32 %[sm0], m0", "s_mov_b32 exec_hi, 0"]
+    l += _row_addr(0, "%[plo]", "%[phi]") + _row_addr(1, "%[plo]", "%[phi]")
+    for r in range(L0):
+        if r + 2 < L0:
+            l += _row_addr(r + 2, "%[plo]", "%[phi]")
+        p = SP + 2 * (r % 4)
+        l.append(f"s_bitcmp1_b32 %[nm], {r}")
+        l.append("s_cselect_b32 exec_lo, -1, 0")
+        l.append(f"s_add_u32 m0, %[img], {PITCH * r}")
+        l.append("s_nop 0")
+        l.append(f"global_load_lds_dwordx4 %[voff], s[{p}:{p + 1}]")
+    l += ["s_mov_b32 m0, %[sm0]", "s_mov_b64 exec, %[sv]"]
+    return l
+
+
+def evict_l0():
+    """... and back: the rows the lanes of %[em] wrote into the write-back image (to_image) leave as one
+    coalesced 512-byte store per row.  All 24 rows of the image are read (into a44..a139: no scalar
+    work, one wait); a row that is not being replaced stores with exec = 0."""
+    l = ["s_mov_b64 %[sv], exec"]
+    for r in range(L0):
+        l.append(f"ds_read_b128 a[{STG + 4 * r}:{STG + 4 * r + 3}], %[va] offset:{PITCH * r}")
+    l.append("s_mov_b32 exec_hi, 0")
+    l += _row_addr(0, "%[plo]", "%[phi]") + _row_addr(1, "%[plo]", "%[phi]")
+    for r in range(L0):
+        if r + 2 < L0:
+            l += _row_addr(r + 2, "%[plo]", "%[phi]")
+        p = SP + 2 * (r % 4)
+        l.append(f"s_bitcmp1_b32 %[em], {r}")
+        l.append("s_cselect_b32 exec_lo, -1, 0")
+        if r == 0:
+            l.append("s_waitcnt lgkmcnt(0)")
+        l.append(f"global_store_dwordx4 %[voff], a[{STG + 4 * r}:{STG + 4 * r + 3}], s[{p}:{p + 1}]")
+    l.append("s_mov_b64 exec, %[sv]")
+    return l
+
+
+def to_image(first, last):
+    """the resident row of the lanes in the mask -> the lane's row of the write-back image in LDS
+    (%[l] = the lane's row address: rows are 528 bytes apart, so the 16 lanes of a ds group hit 16
+    different bank quads)"""
+    return under_mask([f"ds_write_b128 %[l], {W4(q)} offset:{16 * q}" for q in range(first, last)])
+
+
+def from_image(first, last):
+    """the prefetched row of the lanes in the mask: staging image in LDS -> the resident row"""
+    return under_mask([f"ds_read_b128 {W4(q)}, %[l] offset:{16 * q}" for q in range(first, last)])
 
 
 def load_x(l, consume):
@@ -282,9 +361,15 @@ def main():
     blocks = {
         # part A: chunks every row has weights in (layer 1 / final: 33 weights = 9 chunks; what they
         # store beyond is padding that is zero in HBM and in the registers); part B: layer 0 only
-        "GMX_STK_LOAD_A": loads(0, NQA), "GMX_STK_LOAD_B": loads(NQA, NQW),
-        "GMX_STK_STORE_A": stores(0, NQA), "GMX_STK_STORE_B": stores(NQA, NQW),
-        "GMX_STK_ADOPT_A": adopt(0, NQA), "GMX_STK_ADOPT_B": adopt(NQA, NQW),
+        # layer-1 / final rows (144 bytes of weights, <= 9 lanes): lane-private pieces, as they always went
+        "GMX_STK_LOAD_A": loads(0, NQA), "GMX_STK_STORE_A": stores(0, NQA), "GMX_STK_ADOPT_A": adopt(0, NQA),
+        # ... and the rest of a layer-0 row the same way, for launches of few streams (and the per-bit
+        # sessions): with the texture path to itself a wave moves its rows faster lane-private than through
+        # the images (fewer instructions), with all four SIMDs of every CU doing it the images win
+        "GMX_STK_LOAD_B": loads(NQA, NQW), "GMX_STK_STORE_B": stores(NQA, NQW), "GMX_STK_ADOPT_B": adopt(NQA, NQW),
+        # layer-0 rows (24 x 512 bytes): through staging images in LDS, coalesced on the HBM side
+        "GMX_STK_FETCH_L0": fetch_l0(), "GMX_STK_EVICT_L0": evict_l0(),
+        "GMX_STK_TO_IMAGE": to_image(0, NQW), "GMX_STK_FROM_IMAGE": from_image(0, NQW),
         "GMX_STK_FORWARD": forward(), "GMX_STK_FORWARD_EXACT": forward_exact(),
         "GMX_STK_LOAD_X": load_x_only(), "GMX_STK_OUTPUTS_TO_SGPRS": outputs_to_sgprs(),
         "GMX_STK_UPDATE": update(), "GMX_STK_SHRINK": shrink(), "GMX_STK_ZERO": zero_rows(),
@@ -293,6 +378,7 @@ def main():
     for k, v in blocks.items():
         out += emit(k, v)
     out += f"#define GMX_STK_VGPR_LIMIT {RESERVED['v'][0]}\n"
+    out += f"#define GMX_STK_ROW_PITCH {PITCH}\n"
     out += f"#define GMX_STK_SGPR_FIRST {RESERVED['s'][0]}\n"
     out += "// instructions: " + ", ".join(f"{k[8:].lower()} {len(v)}" for k, v in blocks.items()) + "\n"
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gmx_stock_asm.inc")

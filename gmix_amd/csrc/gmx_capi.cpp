@@ -42,7 +42,7 @@ hipError_t gmx_launch_bank_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* ar
                                   unsigned stride0, hipStream_t stream);
 hipError_t gmx_bank_kernel_set_lds(unsigned lds_bytes);
 hipError_t gmx_launch_stock_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_streams,
-                                   unsigned lds_bytes, int has_mask, hipStream_t stream);
+                                   unsigned lds_bytes, int has_mask, int staged, hipStream_t stream);
 hipError_t gmx_launch_single_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_inputs,
                                     int variant, hipStream_t stream);
 hipError_t gmx_launch_wide_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_streams, int has_mask,
@@ -199,6 +199,7 @@ struct gmx_group {
   bool mailbox_on_device = true;   // tests: false keeps the sessions' command blocks in pinned host memory
   bool force_general = false;      // tests: route everything through the general kernel
   bool stock_exact = false;        // tests: stock kernels use their masked forward chains only
+  int stock_staged = -1;           // stock kernel: rows through the LDS images (1), lane-private (0), by stream count (-1)
   bool decay_on_host = false;      // tests: the decay tables always from the host's libm loop
   bool stock_pairs = false;        // batched runs of the stock shape through gmx_wide_kernel<90, 64> (lane pairs)
   int single_variant = 0;          // tests/tuning: lanes per stream of the single-mixer kernel (0 = default)
@@ -710,8 +711,8 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
   else if (wide)
     HIPCHK(gmx_launch_wide_kernel(g->topo_dev, &a, ns, a.mask != nullptr, g->topo.n, g->stream));
   else if (stock)
-    HIPCHK(gmx_launch_stock_kernel(g->topo_dev, &a, ns, (g->topo.lds_misc + 256u) * 4u,
-                                   a.mask != nullptr, g->stream));
+    HIPCHK(gmx_launch_stock_kernel(g->topo_dev, &a, ns, GMX_STK_LDS_BYTES(g->topo.lds_misc),
+                                   a.mask != nullptr, g->stock_staged, g->stream));
   else
     HIPCHK(gmx_launch_bank_kernel(g->topo_dev, &a, ns, g->lds_bytes, a.mask != nullptr, g->topo.l0,
                                   g->topo.l1, g->topo.n_skip, g->topo.has_final,
@@ -1268,6 +1269,14 @@ extern "C" int gmx_debug_force_general(gmx_group* g, int on) {
 
 // Stock kernels: only the masked (exec-per-step) forward chains, which are otherwise the
 // fallback for non-finite values.
+// Tuning / tests: how gmx_stock_kernel moves layer-0 rows (1: staged through LDS, coalesced; 0: lane-private;
+// -1: by the stream count of the launch).  Same floats either way.
+extern "C" int gmx_debug_stock_staged(gmx_group* g, int mode) {
+  if (!g || mode < -1 || mode > 1) return GMX_ERR_INVALID;
+  g->stock_staged = mode;
+  return GMX_OK;
+}
+
 extern "C" int gmx_debug_stock_exact(gmx_group* g, int on) {
   if (!g) return GMX_ERR_INVALID;
   int rc = sessions_close(g, true);

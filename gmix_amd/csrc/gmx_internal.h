@@ -72,6 +72,10 @@ struct GmxRunArgs {
 // slots, used alternately: the payload of the forward whose learn is still to come stays intact
 // while the next one is written (LEARN*_FWD carries both; a wave restarted in between replays the
 // forward from the old slot).
+// LDS of one wave of the stock kernels (gmx_stock.hip): inputs, expf's table, and the two staging images
+// of the 24 layer-0 rows (prefetch, write-back), rows 528 bytes apart
+#define GMX_STK_LDS_BYTES(lds_misc) (((lds_misc) + 256u) * 4u + 2u * 24u * 528u)
+
 #define GMX_MB_FORWARD 1u
 #define GMX_MB_LEARN0 2u      // learn, coded bit 0
 #define GMX_MB_LEARN1 3u      // learn, coded bit 1

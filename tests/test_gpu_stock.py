@@ -15,9 +15,11 @@ def beq(a, b):
                           np.ascontiguousarray(b, np.float32).view(np.uint32))
 
 
-def run(gpu, topo, streams, chunk, force_general, mask=True, learn=True, exact=False, pairs=False):
+def run(gpu, topo, streams, chunk, force_general, mask=True, learn=True, exact=False, pairs=False, staged=-1):
     S, T = len(streams), len(streams[0][3])
     g = gpu.MixerGroup(topo, S)
+    g.L.gmx_debug_stock_staged.argtypes = [C.c_void_p, C.c_int]
+    assert g.L.gmx_debug_stock_staged(g.h, staged) == 0
     g.L.gmx_debug_stock_pairs.argtypes = [C.c_void_p, C.c_int]
     assert g.L.gmx_debug_stock_pairs(g.h, 1 if pairs else 0) == 0
     g.L.gmx_debug_force_general.argtypes = [C.c_void_p, C.c_int]
@@ -49,11 +51,12 @@ def test_stock_kernel_equals_general_kernel_and_oracle(gpu, oracle, kw, mask):
     topo = topology.stock(90)
     S, T = 5, 2600
     streams = [oracle.synth(90, 33, T, seed=1234 + 17 * s, **kw) for s in range(S)]
-    g1, P1, O1 = run(gpu, topo, streams, 700, force_general=False, mask=mask)
+    g1, P1, O1 = run(gpu, topo, streams, 700, force_general=False, mask=mask, staged=1)   # rows through the LDS images
     g2, P2, O2 = run(gpu, topo, streams, 700, force_general=True, mask=mask)
-    assert beq(P1, P2) and beq(O1, O2)
+    g3, P3, O3 = run(gpu, topo, streams, 700, force_general=False, mask=mask, staged=0)   # rows lane-private
+    assert beq(P1, P2) and beq(O1, O2) and beq(P1, P3) and beq(O1, O3)
     for s in range(S):
-        assert g1.export(s) == g2.export(s)
+        assert g1.export(s) == g2.export(s) == g3.export(s)
     ob = oracle.Bank(90, topo.skip, topo.mixers)
     p_ref, o_ref = ob.run(*streams[2])
     assert beq(O1[2], o_ref) and beq(P1[2], p_ref)
