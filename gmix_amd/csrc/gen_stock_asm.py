@@ -63,18 +63,59 @@ def A4(q):
     return f"a[{AB + 4 * q}:{AB + 4 * q + 3}]"
 
 
-WIDE_PREFIXES = ("v_pk_", "v_readlane", "ds_", "global_", "v_accvgpr")
+LLVM_MC = "/opt/rocm/lib/llvm/bin/llvm-mc"
+_DUMMY = {  # operand placeholders -> registers of the right class, for sizing only
+    "sv": "s[10:11]", "mask": "s[12:13]", "seenlo": "s14", "seenhi": "s15", "nm": "s14", "em": "s14", "img": "s15",
+    "sm0": "s16", "p": "v[2:3]", "p0": "v[4:5]", "p1": "v[6:7]", "up2": "v[8:9]", "sc2": "v[8:9]",
+}
+
+
+def _sizes(lines):
+    """Encoded size of every instruction (4 or 8 bytes on gfx950), from the assembler itself."""
+    import re
+    import subprocess
+    text = []
+    for l in lines:
+        text.append(re.sub(r"%\[(\w+)\]", lambda m: _DUMMY.get(m.group(1), "v1"), l))
+    out = subprocess.run([LLVM_MC, "-arch=amdgcn", "-mcpu=gfx950", "-show-encoding"], input="\n".join(text) + "\n",
+                         capture_output=True, text=True, check=True).stdout
+    sz = [len(m.group(1).split(",")) for m in re.finditer(r"encoding: \[([^\]]*)\]", out)]
+    assert len(sz) == len(lines), (len(sz), len(lines))
+    return sz
+
+
+_WIDENABLE = ("v_add_f32 ", "v_sub_f32 ", "v_mul_f32 ", "v_mov_b32 ", "v_cndmask_b32 ")
+
+
+def align8(lines):
+    """Every 8-byte instruction on an 8-byte boundary.  A wave that runs alone on its SIMD pays for an
+    8-byte instruction that straddles a boundary (measured here: the update stream, all packed ops, took
+    12 % longer when the block happened to start at 4 mod 8 -- MI355X_MICROARCH.md notes the same for
+    hand-written streams).  No instruction is added where one can be re-encoded: the nearest preceding
+    4-byte VALU instruction takes its 8-byte VOP3 form (same operation); failing that an s_nop goes in."""
+    sz = _sizes(lines)
+    out, osz, off = [], [], 0
+    for ins, n in zip(lines, sz):
+        if n == 8 and off % 8 == 4:
+            k = len(out) - 1
+            while k >= 0 and osz[k] == 4 and not out[k].startswith(_WIDENABLE):
+                k -= 1
+            if k >= 0 and osz[k] == 4:
+                mnem, rest = out[k].split(" ", 1)
+                out[k], osz[k] = f"{mnem}_e64 {rest}", 8
+            else:
+                out.append("s_nop 0")
+                osz.append(4)
+            off += 4
+        out.append(ins)
+        osz.append(n)
+        off += n
+    assert _sizes(out) == osz
+    return [".p2align 3"] + out
 
 
 def emit(name, lines):
-    if os.environ.get("GMX_STK_ALIGN8") and name in ("GMX_STK_FORWARD", "GMX_STK_UPDATE"):
-        # experiment: every 8-byte instruction on an 8-byte boundary (the assembler pads with s_nop)
-        out = []
-        for l in lines:
-            if l.startswith(WIDE_PREFIXES):
-                out.append(".p2align 3")
-            out.append(l)
-        lines = out
+    lines = align8(lines)
     body = "".join(f'  "{l}\\n\\t" \\\n' for l in lines)
     return f"#define {name} \\\n{body}  \"\"\n\n"
 

@@ -39,8 +39,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
+#include <numeric>
 #include <memory>
 #include <string>
 #include <vector>
@@ -280,6 +283,407 @@ inline void GpuMixerBank::PredictAll(ShortTermMemory& stm) {
   for (int k = 0; k < stm.num_layer1_mixers; ++k) stm.mixer_layer1_outputs[k] = outputs_[j++];
   if (j < outputs_.size()) stm.final_mixer_output = outputs_[j];
 }
+
+// ================================================================================================
+// The same for the two feature models that live on the device next to the mixers (SURVEY.md
+// section 8f ranks 3 and 4): `gmx::GpuIndirect` with Indirect's constructor signature
+// (models/indirect.h:16-18) and `gmx::GpuLstmModel` with LstmModel's (models/lstm-model.h:11-12).
+// Switched in like the mixers (`new Indirect(` -> `new gmx::GpuIndirect(` at its 33 places, `new LstmModel(`
+// -> `new gmx::GpuLstmModel(` once), the reference's Predictor keeps LSTM -> 41 Indirect -> 33 mixers
+// on the MI355X while PPMd, the match models, the context hashes, the coder and the runners stay the
+// reference's own host code (oracle/ref_build builds it as gmix_chain / ref_tester_chain).
+// ================================================================================================
+
+class GpuIndirect;
+
+// All Indirect models of one Predictor: one gmx_indirect with one stream.
+class GpuIndirectBank {
+ public:
+  static std::shared_ptr<GpuIndirectBank> For(ShortTermMemory& stm, LongTermMemory& ltm) {
+    auto& reg = Registry();
+    auto it = reg.find(&ltm);
+    if (it != reg.end())
+      if (auto sp = it->second.lock()) return sp;
+    std::shared_ptr<GpuIndirectBank> sp(new GpuIndirectBank(stm, ltm));
+    reg[&ltm] = sp;
+    return sp;
+  }
+  ~GpuIndirectBank() {
+    if (h_) gmx_indirect_destroy(h_);
+    Registry().erase(&ltm_);
+  }
+  GpuIndirectBank(const GpuIndirectBank&) = delete;
+  GpuIndirectBank& operator=(const GpuIndirectBank&) = delete;
+
+ private:
+  friend class GpuIndirect;
+  GpuIndirectBank(ShortTermMemory& stm, LongTermMemory& ltm) : stm_(stm), ltm_(ltm) {}
+  static std::map<const LongTermMemory*, std::weak_ptr<GpuIndirectBank>>& Registry() {
+    static std::map<const LongTermMemory*, std::weak_ptr<GpuIndirectBank>> r;
+    return r;
+  }
+  static void Check(const char* what, int rc) {
+    if (rc == GMX_OK) return;
+    fprintf(stderr, "\ngmx::GpuIndirect: %s: %s %s\n(the Indirect models run on an MI355X through libgmxmix.so; there is no CPU fallback)\n",
+            what, gmx_strerror(rc), rc == GMX_ERR_HIP ? gmx_last_error() : "");
+    abort();
+  }
+  int Register(GpuIndirect* m, unsigned table_size, float lr, int slot_a, int slot_b, int memory_index) {
+    gmx_indirect_desc d;
+    d.table_size = table_size;
+    d.learning_rate = lr;
+    d.slot_indirect = slot_a;
+    d.slot_run_map = slot_b;
+    descs_.push_back(d);
+    models_.push_back(m);
+    memory_index_.push_back(memory_index);
+    return (int)descs_.size() - 1;
+  }
+  void Ensure() {
+    if (h_) return;
+    // the two state machines are ShortTermMemory's data (short-term-memory.h:144-145): tabulated
+    // here by calling the reference's own Next(), walked on the device
+    uint8_t ns[512], rm[512];
+    for (int s = 0; s < 256; ++s)
+      for (int b = 0; b < 2; ++b) {
+        ns[2 * s + b] = (uint8_t)stm_.nonstationary.Next(s, b);
+        rm[2 * s + b] = (uint8_t)stm_.run_map.Next(s, b);
+      }
+    const char* dev = getenv("GMX_DEVICE");
+    Check("gmx_indirect_create",
+          gmx_indirect_create(&h_, descs_.data(), (int)descs_.size(), ns, rm, 1, dev ? atoi(dev) : 0));
+    contexts_.assign(descs_.size(), 0u);
+    pred_.assign(2 * descs_.size(), 0.f);
+    active_.assign(2 * descs_.size(), 0);
+  }
+  // Tables the reference's LongTermMemory::ReadFromDisk has read since ReadFromDisk was called on the
+  // models go to the device (the indirect section's own format, long-term-memory.cpp:8-32).
+  void Settle() {
+    Ensure();
+    if (!import_pending_) return;
+    import_pending_ = false;
+    std::vector<char> buf;
+    auto put = [&buf](const void* p, size_t n) {
+      const char* c = static_cast<const char*>(p);
+      buf.insert(buf.end(), c, c + n);
+    };
+    for (size_t i = 0; i < descs_.size(); ++i) {
+      auto& mem = ltm_.indirect[memory_index_[i]];
+      std::vector<unsigned int> keys;
+      for (unsigned int k = 0; k < mem.nonstationary_table.size(); ++k)
+        if (mem.nonstationary_table[k] != 255) keys.push_back(k);
+      unsigned int size = (unsigned int)keys.size();
+      put(&size, 4);
+      if (size < mem.nonstationary_table.size() / 3) {
+        for (unsigned int key : keys) {
+          put(&key, 4);
+          put(&mem.nonstationary_table[key], 1);
+          put(&mem.run_map_table[key], 1);
+        }
+      } else {
+        put(mem.nonstationary_table.data(), mem.nonstationary_table.size());
+        put(mem.run_map_table.data(), mem.run_map_table.size());
+      }
+      put(mem.nonstationary_predictions.data(), 256 * 4);
+      put(mem.run_map_predictions.data(), 256 * 4);
+    }
+    Check("gmx_indirect_import", gmx_indirect_import(h_, 0, buf.data(), buf.size()));
+  }
+  // Device -> LongTermMemory::indirect, for the reference's writer.
+  void Stage() {
+    Settle();
+    size_t n = 0;
+    Check("gmx_indirect_export", gmx_indirect_export(h_, 0, nullptr, &n));
+    std::vector<char> buf(n ? n : 1);
+    Check("gmx_indirect_export", gmx_indirect_export(h_, 0, buf.data(), &n));
+    const char* p = buf.data();
+    for (size_t i = 0; i < descs_.size(); ++i) {
+      auto& mem = ltm_.indirect[memory_index_[i]];
+      const size_t size = mem.nonstationary_table.size();
+      unsigned int count;
+      memcpy(&count, p, 4);
+      p += 4;
+      if (count < size / 3) {
+        std::fill(mem.nonstationary_table.begin(), mem.nonstationary_table.end(), (unsigned char)255);
+        std::fill(mem.run_map_table.begin(), mem.run_map_table.end(), (unsigned char)0);
+        for (unsigned int k = 0; k < count; ++k) {
+          unsigned int key;
+          memcpy(&key, p, 4);
+          mem.nonstationary_table[key] = (unsigned char)p[4];
+          mem.run_map_table[key] = (unsigned char)p[5];
+          p += 6;
+        }
+      } else {
+        memcpy(mem.nonstationary_table.data(), p, size);
+        memcpy(mem.run_map_table.data(), p + size, size);
+        p += 2 * size;
+      }
+      memcpy(mem.nonstationary_predictions.data(), p, 256 * 4);
+      memcpy(mem.run_map_predictions.data(), p + 1024, 256 * 4);
+      p += 2048;
+    }
+  }
+  void PredictAll(ShortTermMemory& stm);
+  void LearnAll(const ShortTermMemory& stm) {
+    Settle();
+    Check("gmx_indirect_learn", gmx_indirect_learn(h_, 0, stm.new_bit));
+  }
+  void CopyFrom(GpuIndirectBank& o) {
+    o.Settle();
+    Ensure();
+    import_pending_ = false;
+    Check("gmx_indirect_copy", gmx_indirect_copy(h_, 0, o.h_, 0));
+  }
+
+  ShortTermMemory& stm_;
+  LongTermMemory& ltm_;
+  gmx_indirect* h_ = nullptr;
+  std::vector<gmx_indirect_desc> descs_;
+  std::vector<GpuIndirect*> models_;
+  std::vector<int> memory_index_;
+  std::vector<uint32_t> contexts_;
+  std::vector<float> pred_;
+  std::vector<uint8_t> active_;
+  bool import_pending_ = false;
+};
+
+class GpuIndirect : public Model {
+ public:
+  // models/indirect.h:16-18, argument for argument.
+  GpuIndirect(ShortTermMemory& short_term_memory, LongTermMemory& long_term_memory, float learning_rate,
+              unsigned int table_size, unsigned int& context, std::string description, bool enable_analysis)
+      : context_(context), bank_(GpuIndirectBank::For(short_term_memory, long_term_memory)) {
+    // indirect.cpp:10-26: the registrations Indirect::Indirect makes (the tables in LongTermMemory are
+    // the staging area of the reference's serialisers here, as they are for the mixers)
+    const int a = short_term_memory.AddPrediction(description + "-indirect", enable_analysis, this);
+    const int b = short_term_memory.AddPrediction(description + "-run_map", enable_analysis, this);
+    const int memory_index = (int)long_term_memory.indirect.size();
+    long_term_memory.indirect.push_back(IndirectMemory(table_size * 256 + 1));
+    for (int i = 0; i < 256; ++i) {
+      long_term_memory.indirect.back().nonstationary_predictions[i] = 0;
+      long_term_memory.indirect.back().run_map_predictions[i] = 0;
+    }
+    index_ = bank_->Register(this, table_size, learning_rate, a, b, memory_index);
+  }
+  // The context of a model may come from the model just in front of it (IndirectHash and SkipContext
+  // sit between the Indirect models, predictor.cpp:78-250), so the bank runs when the LAST of them is
+  // called: every context is final by then, and nothing in between reads an Indirect prediction.
+  void Predict(ShortTermMemory& short_term_memory, const LongTermMemory&) override {
+    if (index_ + 1 == (int)bank_->models_.size()) bank_->PredictAll(short_term_memory);
+  }
+  void Learn(const ShortTermMemory& short_term_memory, LongTermMemory&) override {
+    if (index_ == 0) bank_->LearnAll(short_term_memory);
+  }
+  void WriteToDisk(std::ofstream*) override {  // indirect.h:23: nothing in .short; stage for the .long writer
+    if (index_ == 0) bank_->Stage();
+  }
+  void ReadFromDisk(std::ifstream*) override {
+    bank_->Ensure();
+    bank_->import_pending_ = true;
+  }
+  void Copy(const MemoryInterface* m) override {
+    const GpuIndirect* orig = static_cast<const GpuIndirect*>(m);
+    if (index_ == 0) bank_->CopyFrom(*orig->bank_);
+  }
+  unsigned long long GetMemoryUsage(const ShortTermMemory&, const LongTermMemory&) override {  // indirect.cpp:71-78
+    bank_->Settle();
+    uint64_t v = 0;
+    GpuIndirectBank::Check("gmx_indirect_memory_usage", gmx_indirect_memory_usage(bank_->h_, index_, &v));
+    return v;
+  }
+  unsigned int context() const { return context_; }
+
+ private:
+  unsigned int& context_;  // aliases a field of the Predictor's blackboard (indirect.h:31)
+  std::shared_ptr<GpuIndirectBank> bank_;
+  int index_;
+};
+
+inline void GpuIndirectBank::PredictAll(ShortTermMemory& stm) {
+  Settle();
+  for (size_t i = 0; i < models_.size(); ++i) contexts_[i] = models_[i]->context();
+  Check("gmx_indirect_forward",
+        gmx_indirect_forward(h_, 0, contexts_.data(), stm.bit_context, pred_.data(), active_.data()));
+  // What 41 x Indirect::Predict leave on the blackboard (indirect.cpp:35-44 through SetLogitPrediction,
+  // short-term-memory.cpp:193-197): an active model stores its logit and joins active_models, a zero
+  // logit is stored but not active, a model that has never seen its state stores nothing -- the bank
+  // then reports the slot's old value, which is only written back when it is that stored zero.
+  for (size_t i = 0; i < descs_.size(); ++i) {
+    const int slot[2] = {descs_[i].slot_indirect, descs_[i].slot_run_map};
+    for (int k = 0; k < 2; ++k) {
+      const float v = pred_[2 * i + k];
+      if (active_[2 * i + k]) {
+        stm.predictions[slot[k]] = v;
+        stm.active_models.push_back(slot[k]);
+      } else if (v == 0) {
+        stm.predictions[slot[k]] = v;
+      }
+    }
+  }
+  // the reference's models push their (ascending) indices as they are called; the match models sit
+  // between the Indirect groups, so restore that order
+  std::sort(stm.active_models.begin(), stm.active_models.end());
+}
+
+// LstmModel (models/lstm-model.cpp) with Lstm(256, 256, 50, 1, 100, 0.03, 10) on the device: the byte-level
+// network once per byte through gmx_lstm_forward / gmx_lstm_perceive, the bit-level range coding of
+// the byte distribution (lstm-model.cpp:34-48) on the host as in the reference.
+class GpuLstmModel : public Model {
+ public:
+  static constexpr int kCells = 50, kInputs = 563, kHorizon = 100, kOut = 256, kHidden = 51;
+  // models/lstm-model.h:11-12
+  GpuLstmModel(ShortTermMemory& short_term_memory, LongTermMemory& long_term_memory, bool enable_analysis)
+      : ltm_(long_term_memory), top_(255), mid_(127), bot_(0), probs_(1.0 / 256, 256) {
+    // What the constructors behind Lstm(256, 256, 50, 1, 100, 0.03, 10, ltm) do to LongTermMemory
+    // (lstm.cpp:26-29, lstm-layer.cpp:57-59, :179-194): the output-layer ring, three gate matrices,
+    // their initial values drawn from rand() in the reference's interleaved order.
+    ltm_.lstm_output_layer.resize(
+        kHorizon, std::valarray<std::valarray<float>>(std::valarray<float>(kHidden), kOut));
+    first_layer_ = (int)ltm_.neuron_layer_weights.size();
+    for (int g = 0; g < 3; ++g) ltm_.neuron_layer_weights.push_back(NeuronLayerWeights(kInputs, kCells));
+    const float val = std::sqrt(6.0f / float(256 + 256));
+    const float low = -val, range = 2 * val;
+    for (int i = 0; i < kCells; ++i) {
+      for (int j = 0; j < kInputs; ++j)
+        for (int g = 0; g < 3; ++g)
+          ltm_.neuron_layer_weights[first_layer_ + g].weights[i][j] =
+              low + (static_cast<float>(rand()) / static_cast<float>(RAND_MAX)) * range;
+      ltm_.neuron_layer_weights[first_layer_].weights[i][kInputs - 1] = 1;
+    }
+    prediction_index_ = short_term_memory.AddPrediction("LSTM", enable_analysis, this);
+    short_term_memory.models_with_skip_connection.push_back(prediction_index_);
+  }
+  ~GpuLstmModel() override {
+    if (h_) gmx_lstm_destroy(h_);
+  }
+  void Predict(ShortTermMemory& short_term_memory, const LongTermMemory&) override {  // lstm-model.cpp:17-49
+    if (short_term_memory.recent_bits == 1) {
+      Settle();
+      uint32_t ctx = 0;
+      Check("gmx_lstm_forward", gmx_lstm_forward(h_, 0, (int)short_term_memory.last_byte,
+                                                  &short_term_memory.ppm_predictions[0], &probs_[0], &ctx));
+      short_term_memory.lstm_prediction_context = ctx;
+      top_ = 255;
+      bot_ = 0;
+    } else if (short_term_memory.new_bit) {
+      bot_ = mid_ + 1;
+    } else {
+      top_ = mid_;
+    }
+    mid_ = bot_ + ((top_ - bot_) / 2);
+    const float num = std::accumulate(&probs_[mid_ + 1], &probs_[top_ + 1], 0.0f);
+    const float denom = std::accumulate(&probs_[bot_], &probs_[mid_ + 1], num);
+    if (denom != 0) short_term_memory.SetPrediction(num / denom, prediction_index_);
+  }
+  void Learn(const ShortTermMemory& short_term_memory, LongTermMemory&) override {  // lstm-model.cpp:51-60
+    const int current_byte = short_term_memory.recent_bits * 2 + short_term_memory.new_bit;
+    if (current_byte >= 256) {
+      Settle();
+      Check("gmx_lstm_perceive", gmx_lstm_perceive(h_, 0, current_byte - 256));
+    }
+  }
+  // lstm-model.cpp:62-68 and everything behind it: the device writes the model's stretch of the .short
+  // file; the range state is this object's own.  The LSTM section of the .long file is the reference's
+  // to write (long-term-memory.cpp:57-67), from the arrays staged here.
+  void WriteToDisk(std::ofstream* s) override {
+    Settle();
+    size_t nl = 0, ns = 0;
+    Check("gmx_lstm_export", gmx_lstm_export(h_, 0, nullptr, &nl, nullptr, &ns));
+    std::vector<char> l(nl), sh(ns);
+    Check("gmx_lstm_export", gmx_lstm_export(h_, 0, l.data(), &nl, sh.data(), &ns));
+    memcpy(sh.data(), &top_, 4);
+    memcpy(sh.data() + 4, &mid_, 4);
+    memcpy(sh.data() + 8, &bot_, 4);
+    memcpy(sh.data() + 12, &probs_[0], 1024);
+    s->write(sh.data(), ns);
+    const float* f = reinterpret_cast<const float*>(l.data());
+    for (auto& x : ltm_.lstm_output_layer)
+      for (auto& y : x) {
+        memcpy(&y[0], f, 4 * y.size());
+        f += y.size();
+      }
+    for (int g = 0; g < 3; ++g)
+      for (auto& y : ltm_.neuron_layer_weights[first_layer_ + g].weights) {
+        memcpy(&y[0], f, 4 * y.size());
+        f += y.size();
+      }
+  }
+  void ReadFromDisk(std::ifstream* s) override {  // lstm-model.cpp:70-76
+    Ensure();
+    size_t nl = 0, ns = 0;
+    Check("gmx_lstm_export", gmx_lstm_export(h_, 0, nullptr, &nl, nullptr, &ns));
+    short_in_.resize(ns);
+    s->read(short_in_.data(), ns);
+    memcpy(&top_, short_in_.data(), 4);
+    memcpy(&mid_, short_in_.data() + 4, 4);
+    memcpy(&bot_, short_in_.data() + 8, 4);
+    memcpy(&probs_[0], short_in_.data() + 12, 1024);
+    import_pending_ = true;  // the weights follow when LongTermMemory::ReadFromDisk has run
+  }
+  void Copy(const MemoryInterface* m) override {  // lstm-model.cpp:78-85
+    GpuLstmModel* orig = const_cast<GpuLstmModel*>(static_cast<const GpuLstmModel*>(m));
+    orig->Settle();
+    Ensure();
+    import_pending_ = false;
+    Check("gmx_lstm_copy", gmx_lstm_copy(h_, 0, orig->h_, 0));
+    top_ = orig->top_;
+    mid_ = orig->mid_;
+    bot_ = orig->bot_;
+    probs_ = orig->probs_;
+  }
+  unsigned long long GetMemoryUsage(const ShortTermMemory&, const LongTermMemory&) override {
+    Ensure();
+    uint64_t v = 0;
+    Check("gmx_lstm_memory_usage", gmx_lstm_memory_usage(h_, &v));
+    return v;
+  }
+
+ private:
+  static void Check(const char* what, int rc) {
+    if (rc == GMX_OK) return;
+    fprintf(stderr, "\ngmx::GpuLstmModel: %s: %s %s\n(the LSTM runs on an MI355X through libgmxmix.so; there is no CPU fallback)\n",
+            what, gmx_strerror(rc), rc == GMX_ERR_HIP ? gmx_last_error() : "");
+    abort();
+  }
+  std::vector<char> LongBytes() const {  // the LSTM section as LongTermMemory writes it
+    std::vector<char> l;
+    auto put = [&l](const std::valarray<float>& y) {
+      const char* c = reinterpret_cast<const char*>(&y[0]);
+      l.insert(l.end(), c, c + 4 * y.size());
+    };
+    for (auto& x : ltm_.lstm_output_layer)
+      for (auto& y : x) put(y);
+    for (int g = 0; g < 3; ++g)
+      for (auto& y : ltm_.neuron_layer_weights[first_layer_ + g].weights) put(y);
+    return l;
+  }
+  void Ensure() {
+    if (h_) return;
+    const char* dev = getenv("GMX_DEVICE");
+    Check("gmx_lstm_create", gmx_lstm_create(&h_, 1, dev ? atoi(dev) : 0));
+    std::vector<float> w((size_t)3 * kCells * kInputs);
+    for (int g = 0; g < 3; ++g)
+      for (int i = 0; i < kCells; ++i)
+        memcpy(&w[((size_t)g * kCells + i) * kInputs], &ltm_.neuron_layer_weights[first_layer_ + g].weights[i][0],
+               4 * kInputs);
+    Check("gmx_lstm_set_weights", gmx_lstm_set_weights(h_, 0, w.data()));
+  }
+  void Settle() {
+    Ensure();
+    if (!import_pending_) return;
+    import_pending_ = false;
+    std::vector<char> l = LongBytes();
+    Check("gmx_lstm_import", gmx_lstm_import(h_, 0, l.data(), l.size(), short_in_.data(), short_in_.size()));
+  }
+
+  LongTermMemory& ltm_;
+  gmx_lstm* h_ = nullptr;
+  int first_layer_ = 0;
+  int top_, mid_, bot_, prediction_index_;
+  std::valarray<float> probs_;
+  std::vector<char> short_in_;
+  bool import_pending_ = false;
+};
 
 }  // namespace gmx
 
