@@ -9,27 +9,21 @@ import os
 
 import pytest
 
-from dropin_common import REF, compare, run_pair
+from dropin_common import REF, compare, run_all
 
 
 @pytest.mark.slow
-def test_reference_tester_with_adapter_equals_stock(tmp_path):
-    for exe in ("ref_tester_strict", "ref_tester_shim"):
+def test_reference_tester_with_adapters_equals_stock(tmp_path):
+    """Three builds of the reference's tester at once on the same bytes: stock; mixers through
+    gmx::GpuMixer; and the whole device chain -- LstmModel -> gmx::GpuLstmModel and the 41 Indirect ->
+    gmx::GpuIndirect as well (the bank that runs when the LAST Indirect model is called, active_models back
+    in index order, the .long sections written by the reference's own serialiser from what the adapters
+    staged).  The chain build runs without TestGeneration: it checkpoints after a Predict whose byte is
+    never perceived, which the device LSTM bank refuses (include/gmxmix.h)."""
+    exes = ("ref_tester_strict", "ref_tester_shim", "ref_tester_chain_shim")
+    for exe in exes:
         if not os.path.exists(os.path.join(REF, exe)):
             pytest.skip(f"oracle/_ref/{exe} not built (needs /root/reference: make -C oracle/ref_build dropin)")
-    da, db = run_pair("ref_tester_strict", "ref_tester_shim", 2500, 300, tmp_path)
-    compare(da, db)
-
-
-@pytest.mark.slow
-def test_reference_tester_with_the_whole_device_chain_adapters_equals_stock(tmp_path):
-    """... and with LstmModel -> gmx::GpuLstmModel and the 41 Indirect -> gmx::GpuIndirect as well (their
-    C-ABI calls answered by the oracle's restatements, tests/cpp/gmx_abi_oracle_shim2.c): the bank that runs
-    when the LAST Indirect model is called, active_models back in index order, the .long sections of both
-    written by the reference's own serialiser from what the adapters staged.  Without TestGeneration: it
-    checkpoints after a Predict whose byte is never perceived, which the device LSTM bank refuses."""
-    for exe in ("ref_tester_strict", "ref_tester_chain_shim"):
-        if not os.path.exists(os.path.join(REF, exe)):
-            pytest.skip(f"oracle/_ref/{exe} not built (needs /root/reference: make -C oracle/ref_build dropin)")
-    da, db = run_pair("ref_tester_strict", "ref_tester_chain_shim", 1200, 0, tmp_path)
-    compare(da, db, generation=False)
+    stock, mixers, chain = run_all([(exes[0], 300), (exes[1], 300), (exes[2], 0)], 1500, tmp_path)
+    compare(stock, mixers)
+    compare(stock, chain, generation=False)
