@@ -334,16 +334,32 @@ static int build_topology(const gmx_topology* t, GmxTopoDev* o) {
   // them differ by at most l0-1 weights), every layer-1/final row 64 floats (one per lane).
   for (int j = 0; j < o->l0; ++j) o->mx[j].stride = o->mx[o->l0 - 1].stride;
   for (int j = o->l0; j < o->m; ++j) o->mx[j].stride = 64;
-  // bank layout in HBM: weight tables, then row-step tables, then per-mixer scalars
+  // bank layout in HBM: weight tables, then row-step tables, then per-mixer scalars.
+  // The reference's own shape keeps each row's step counter INSIDE the row instead, in the last 8
+  // bytes of its zero padding (every row there ends in at least one whole spare quad: 113 of 128,
+  // 33 of 64 floats): a separate counter costs a 64-byte sector each way per row change -- 19 % of
+  // that shape's traffic when every row changes every bit -- while the row's last sector travels
+  // anyway.  The spare quad is never moved as weights by any kernel of that shape.
+  const bool fold = o->n == 90 && o->l0 == 24 && o->l1 == 8 && o->n_skip == 1 && o->has_final &&
+                    o->mx[23].stride == 128;
   uint64_t off = 0;
   for (int j = 0; j < o->m; ++j) {
     o->mx[j].w_off = off;
     off += (uint64_t)o->mx[j].table_size * o->mx[j].stride * 4u;
   }
   for (int j = 0; j < o->m; ++j) {
-    o->mx[j].rs_off = off;
-    off += (uint64_t)o->mx[j].table_size * 8u;
-    off = round_up64(off, 128);
+    GmxMixerDev& x = o->mx[j];
+    x.rs_folded = fold ? 1u : 0u;
+    if (fold) {
+      if (x.stride < round_up(x.weight_size, 4) + 4u) return GMX_ERR_INVALID;
+      x.rs_off = x.w_off + (uint64_t)x.stride * 4u - 8u;
+      x.rs_pitch = x.stride * 4u;
+    } else {
+      x.rs_off = off;
+      x.rs_pitch = 8u;
+      off += (uint64_t)x.table_size * 8u;
+      off = round_up64(off, 128);
+    }
   }
   o->scal_off = off;
   off += (uint64_t)o->m * 24u;
@@ -1070,10 +1086,9 @@ extern "C" int gmx_bank_export(gmx_group* g, int stream, void* long_buf, size_t*
   // mixer section of LongTermMemory::WriteToDisk (long-term-memory.cpp:35-55)
   size_t need_long = 0;
   for (int j = 0; j < t.m; ++j) {
-    const uint64_t* rs = (const uint64_t*)(img.data() + t.mx[j].rs_off);
     need_long += 8;
     for (uint32_t r = 0; r < t.mx[j].table_size; ++r)
-      if (rs[r]) need_long += 12 + 4 * (size_t)t.mx[j].weight_size;
+      if (*GMX_RS_PTR(img.data(), t.mx[j], r)) need_long += 12 + 4 * (size_t)t.mx[j].weight_size;
   }
   const bool fits = long_buf && short_buf && *long_bytes >= need_long && *short_bytes >= need_short;
   *long_bytes = need_long;
@@ -1084,19 +1099,19 @@ extern "C" int gmx_bank_export(gmx_group* g, int stream, void* long_buf, size_t*
   uint8_t* o = (uint8_t*)long_buf;
   for (int j = 0; j < t.m; ++j) {
     const GmxMixerDev& x = t.mx[j];
-    const uint64_t* rs = (const uint64_t*)(img.data() + x.rs_off);
     const float* w = (const float*)(img.data() + x.w_off);
     uint32_t cnt = 0;
     for (uint32_t r = 0; r < x.table_size; ++r)
-      if (rs[r]) ++cnt;
+      if (*GMX_RS_PTR(img.data(), x, r)) ++cnt;
     uint32_t input_size = cnt ? x.weight_size : 0;
     memcpy(o, &cnt, 4);
     memcpy(o + 4, &input_size, 4);
     o += 8;
     for (uint32_t r = 0; r < x.table_size; ++r) {
-      if (!rs[r]) continue;
+      const uint64_t steps = *GMX_RS_PTR(img.data(), x, r);
+      if (!steps) continue;
       memcpy(o, &r, 4);
-      memcpy(o + 4, &rs[r], 8);
+      memcpy(o + 4, &steps, 8);
       memcpy(o + 12, w + (size_t)r * x.stride, 4 * (size_t)x.weight_size);
       o += 12 + 4 * (size_t)x.weight_size;
     }
@@ -1125,15 +1140,15 @@ extern "C" int gmx_bank_import(gmx_group* g, int stream, const void* long_buf, s
     memcpy(&input_size, p + 4, 4);
     p += 8;
     if (cnt > x.table_size || (cnt && input_size != x.weight_size)) return GMX_ERR_FORMAT;
-    uint64_t* rs = (uint64_t*)(img.data() + x.rs_off);
     float* w = (float*)(img.data() + x.w_off);
     for (uint32_t i = 0; i < cnt; ++i) {
       if ((size_t)(end - p) < 12 + 4 * (size_t)input_size) return GMX_ERR_FORMAT;
       uint32_t r;
       memcpy(&r, p, 4);
       if (r >= x.table_size) return GMX_ERR_FORMAT;
-      memcpy(&rs[r], p + 4, 8);
-      if (rs[r] == 0) return GMX_ERR_FORMAT;  // a stored row has been learned at least once
+      uint64_t* const rs = GMX_RS_PTR(img.data(), x, r);
+      memcpy(rs, p + 4, 8);
+      if (*rs == 0) return GMX_ERR_FORMAT;  // a stored row has been learned at least once
       memcpy(w + (size_t)r * x.stride, p + 12, 4 * (size_t)input_size);
       p += 12 + 4 * (size_t)input_size;
     }

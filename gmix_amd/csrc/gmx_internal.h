@@ -24,8 +24,15 @@ struct GmxMixerDev {
   int32_t out_index;     // index inside its layer (output_index_ for layers 0/1)
   float lr;              // learning_rate_
   uint64_t w_off;        // byte offset of the weight table inside a bank
-  uint64_t rs_off;       // byte offset of the per-row step counters (MixerData::steps)
+  uint64_t rs_off;       // byte offset of row 0's step counter (MixerData::steps) ...
+  uint32_t rs_pitch;     // ... and the byte distance to the next row's: 8 (a table of its own) or the row
+                         // length (folded: the counter is the last 8 bytes of the row's zero padding)
+  uint32_t rs_folded;
 };
+
+// Address of the step counter of row `row` of mixer `mx` in the bank at `bank`.
+#define GMX_RS_PTR(bank, mx, row) \
+  ((uint64_t*)((uint8_t*)(bank) + (mx).rs_off + (uint64_t)(row) * (mx).rs_pitch))
 
 struct GmxTopoDev {
   int32_t n, n_pad, n_skip, m, l0, l1, has_final, mask_words;

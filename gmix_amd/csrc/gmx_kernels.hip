@@ -181,7 +181,7 @@ gmx_bank_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
     max_steps = scal[1];
     seen_cnt = scal[2];
   }
-  uint64_t* const rs_tab = (uint64_t*)(bank + d.rs_off);
+  uint8_t* const rs_base = bank + d.rs_off;  // row r's step counter: rs_base + r * d.rs_pitch (gmx_internal.h)
   uint8_t* const w_tab = bank + d.w_off;
 
   // Geometry of the layer-0 update pass: rows of <= 64 / <= 128 floats are processed 4 / 2
@@ -224,7 +224,7 @@ gmx_bank_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
       const uint32_t tag_c = cur ? tag1 : tag0, tag_o = cur ? tag0 : tag1;
       need = is_mx && row_n != tag_c && row_n != tag_o;
       const uint32_t dst = d.lds_off + (cur ? 0u : d.pitch);  // the slot that is not in use
-      if (need) gmx_vld8(rs_ld, rs_tab + row_n);
+      if (need) gmx_vld8(rs_ld, (const uint64_t*)(rs_base + (uint64_t)row_n * d.rs_pitch));
       uint64_t nm = __ballot(need);
       const uint32_t lds_base = gmx_lds_addr(lds);
       // every lane works out where its own mixer's row lives and where it goes; the issue
@@ -414,7 +414,7 @@ gmx_bank_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
           if (rs_new > max_steps) max_steps = rs_new;
           if (rs_c == 0) ++seen_cnt;  // FindOrCreateMixerData (mixer.cpp:44-46)
           if (cur) rs1 = rs_new; else rs0 = rs_new;
-          gmx_vst8(rs_tab + row_c, rs_new);
+          gmx_vst8((uint64_t*)(rs_base + (uint64_t)row_c * d.rs_pitch), rs_new);
         }
         const float shrink = 1.0f - 3.0e-6f;
         const uint64_t grow = (uint64_t)w_tab + (uint64_t)row_c * d.stride * 4u;  // this mixer's row in HBM
@@ -427,7 +427,8 @@ gmx_bank_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
           // weight_size see x = 0 (their stored weights are the zero padding and stay zero),
           // lanes past the stored row only skip the HBM store (exec mask inside the asm).
           const uint32_t c = 4u * (uint32_t)lr_;
-          const uint64_t st_mask = __ballot(c < stride0);
+          // (a folded step counter lives in the row's last quad: that quad is never stored as weights)
+          const uint64_t st_mask = __ballot(c < stride0 - (d.rs_folded ? 4u : 0u));
 #pragma unroll
           for (int m0 = 0; m0 < L0; m0 += RP) {
             const int m = m0 + sub;
@@ -516,7 +517,7 @@ gmx_bank_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
           w = w - u * x;
           w = sh ? w * shrink : w;
           lds[so + c] = w;
-          gmx_vst4(g + (uint64_t)c * 4u, w);
+          if (c < 60 || !d.rs_folded) gmx_vst4(g + (uint64_t)c * 4u, w);  // the last quad may hold the step counter
         }
       }
     }
