@@ -1,0 +1,43 @@
+"""bench.py's one JSON line: the driver's contract fields, `roofline`, `cpu_baseline`, and under `also`
+the north_star's other shapes -- on a reduced headline size so that the test takes half a minute."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_carries_the_contract(gpu):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--streams", "1024", "--bits", "256", "--steps", "4",
+                        "--cpu-sample-bits", "200000"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "also"):
+        assert k in d, k
+    assert d["unit"] == "bits/s" and d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "configs[1]" in d["config"]["workload"] and "model" not in d["config"]
+    assert set(d["also"]) == {"synth3", "stock_held", "stock_fresh", "stock_S1"}
+    for name, e in [("headline", d)] + list(d["also"].items()):
+        assert "error" not in e, (name, e)
+        ro = e["roofline"]
+        assert ro["bound"] == "hbm" and ro["peak"] == 8000.0 and ro["unit"] == "GB/s"
+        assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12 and 0 < ro["frac"] < 1
+        assert ro["bytes_per_launch"] == ro["algorithmic_bytes_per_bit"] * e["config"]["streams_per_gpu"] * \
+            e["config"]["bits_per_stream_per_step"]
+        # the live HIP-event figure and the wall clock tell the same story
+        assert ro["kernel_ms_avg"] <= e["ms_per_step"] * 1.02
+        assert e["value"] > 0 and e["cpu_baseline"]["cores"] == 1 and e["cpu_baseline"]["kind"] in ("reference", "port")
+        assert e["cpu_baseline"]["value"] > 1e4
+    assert d["also"]["synth3"]["config"]["n_inputs"] == 256 and d["also"]["synth3"]["config"]["mixers"] == "24/8/1"
+    assert d["also"]["stock_S1"]["config"]["streams_per_gpu"] == 1
