@@ -1,0 +1,22 @@
+#!/bin/bash
+# The reference's own compressor end to end (`gmix -c`), stock and with its mixers (and LSTM + Indirect
+# models) on the MI355X: wall time and bits/s on the same text, outputs compared.  The binaries are the
+# reference built by oracle/ref_build (test infrastructure); the text is this repository's own markdown.
+#   bash scripts/whole_pipeline_timing.sh [bytes=100000]
+cd "${GRAFT_REPO_ROOT:-.}"
+N=${1:-100000}
+W=$(mktemp -d)
+cat SURVEY.md DESIGN.md INTEGRATION.md PAPERS.md SNIPPETS.md 2>/dev/null | head -c $N > $W/in
+echo "input: $(wc -c < $W/in) bytes of text; host: $(grep -m1 'model name' /proc/cpuinfo | cut -d: -f2)"
+for exe in gmix_strict gmix_gpu gmix_chain; do
+  [ "$exe" = gmix_chain ] && [ "$N" -gt 20000 ] && head -c 20000 $W/in > $W/in_c && IN=$W/in_c || IN=$W/in
+  mkdir -p $W/$exe && cd $W/$exe
+  s=$(date +%s.%N)
+  timeout -k 10 900 $OLDPWD/oracle/_ref/$exe -c $IN $W/$exe/out > /dev/null 2>&1
+  rc=$?
+  e=$(date +%s.%N)
+  cd $OLDPWD
+  python3 -c "import sys; n=$(wc -c < $IN); t=$e-$s; print('%-12s rc %d  %7d bytes -> %6d  %.1f s  %.0f bits/s  %.1f us/bit  md5 %s' % ('$exe', $rc, n, $(wc -c < $W/$exe/out), t, 8*n/t, t/(8*n)*1e6, '$(md5sum < $W/$exe/out | cut -c1-12)'))"
+done
+cmp $W/gmix_strict/out $W/gmix_gpu/out && echo "gmix_gpu output == gmix_strict output"
+rm -rf $W
