@@ -1389,7 +1389,22 @@ extern "C" int gmx_group_set_cu_mask(gmx_group* g, const uint32_t* mask, int n_w
 extern "C" int gmx_indirect_set_cu_mask(gmx_indirect* ib, const uint32_t* mask, int n_words) {
   if (!ib || n_words < 0 || (n_words > 0 && !mask)) return GMX_ERR_INVALID;
   HIPCHK(hipSetDevice(ib->device));
+  {
+    int rcs = ind_sessions_close(ib);
+    if (rcs) return rcs;
+  }
   return stream_with_cu_mask(&ib->stream, mask, n_words);
+}
+
+// Tests / tuning: the per-bit surface of an Indirect bank through persistent sessions (1, default) or a
+// kernel launch per call (0).  Same floats either way.
+extern "C" int gmx_debug_indirect_use_sessions(gmx_indirect* ib, int on) {
+  if (!ib) return GMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(ib->device));
+  int rc = ind_sessions_close(ib);
+  if (rc) return rc;
+  ib->use_sessions = on != 0;
+  return GMX_OK;
 }
 extern "C" int gmx_lstm_set_cu_mask(gmx_lstm* l, const uint32_t* mask, int n_words) {
   if (!l || n_words < 0 || (n_words > 0 && !mask)) return GMX_ERR_INVALID;

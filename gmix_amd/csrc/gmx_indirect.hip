@@ -275,6 +275,156 @@ extern "C" hipError_t gmx_launch_indirect_kernel(const GmxIndDev* dv, const GmxI
                : ind_launch_as<false, false, false>(dv, args, n_streams, lds_bytes, stream);
 }
 
+// ---------------------------------------------------------------------------------------
+// Session kernel: Indirect::Predict / Indirect::Learn one bit at a time without a kernel launch per
+// call (a decoder learns the bit from Predict's own result, coder/decoder.cpp:19-39).  One persistent
+// wave per stream, the protocol of gmx_stock_session_kernel: commands from a mailbox, the logit
+// tables resident in LDS, the table entry of the bit in a register between forward and learn; the
+// wave leaves -- writing the logit tables and the slot values back -- on GMX_MB_STOP or after
+// `idle_ticks` of s_memrealtime without a command.  `replay_forward`: started between the forward and
+// the learn of a bit, it recomputes the forward from the contexts still in the mailbox first.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+gmx_indirect_session_kernel(const GmxIndDev* __restrict__ dv, uint8_t* banks, int stream, GmxIndMbCmd* mc,
+                            GmxIndMbReply* mr, unsigned long long idle_ticks, int replay_forward) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x;
+  const int K = dv->k;
+  uint8_t* const bank = banks + (uint64_t)stream * dv->bank_bytes;
+  float* const ptab = lds;
+  uint64_t* const s_tab = (uint64_t*)(lds + (size_t)K * 512);
+  uint8_t* const nsn = (uint8_t*)(s_tab + 32);
+  uint8_t* const rmn = nsn + 512;
+  float* const gp = (float*)(bank + dv->pred_off);
+  for (int i = lane; i < K * 512; i += 64) ptab[i] = gp[i];
+  if (lane < 32) s_tab[lane] = gmx_exp2f_tab[lane];
+  for (int i = lane; i < 512; i += 64) {
+    nsn[i] = dv->ns_next[i];
+    rmn[i] = dv->rm_next[i];
+  }
+  __syncthreads();
+  const bool on = lane < K;
+  const int ml = on ? lane : 0;  // idle lanes mirror model 0 (same values to the same addresses)
+  const GmxIndModelDev d = dv->m[ml];
+  uint16_t* const tab = (uint16_t*)(bank + d.tab_off);
+  float* const slots = (float*)(bank + dv->slots_off);
+  float va = slots[2 * ml], vb = slots[2 * ml + 1];
+  float* const nsp = ptab + (size_t)ml * 512;
+  float* const rmp = nsp + 256;
+  volatile GmxIndMbReply* const vr = mr;
+  const volatile GmxIndMbCmd* const vc = mc;
+
+  uint32_t seen = __hip_atomic_load(&mr->done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  uint32_t idx = 0, e = 0;
+  bool have_fwd = false, dirty = false;
+  bool replay = replay_forward != 0;
+  uint32_t exit_state = GMX_MB_EXIT_IDLE;
+  for (;;) {
+    uint32_t word = seen, cmd = GMX_MB_FORWARD;
+    uint32_t slot = (uint32_t)(replay_forward - 1) & 1u;
+    if (!replay) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      bool idle = false;
+      for (;;) {
+        word = __hip_atomic_load(&mc->cmd_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (word != seen) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > idle_ticks) { idle = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (idle) break;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+      cmd = word & GMX_MB_CMD_MASK;
+      slot = (word >> GMX_MB_SLOT_SHIFT) & 1u;
+    }
+    if (cmd == GMX_MB_STOP) { exit_state = GMX_MB_EXIT_STOP; seen = word; break; }
+    const bool with_learn = cmd == GMX_MB_LEARN0 || cmd == GMX_MB_LEARN1 || cmd == GMX_MB_LEARN0_FWD ||
+                            cmd == GMX_MB_LEARN1_FWD;
+    const bool with_forward = cmd == GMX_MB_FORWARD || cmd == GMX_MB_LEARN0_FWD || cmd == GMX_MB_LEARN1_FWD;
+    if (with_learn && have_fwd) {
+      // ---- Indirect::Learn (indirect.cpp:48-69) on the entry the forward latched ------------
+      const int bit = (cmd == GMX_MB_LEARN1 || cmd == GMX_MB_LEARN1_FWD) ? 1 : 0;
+      const uint32_t ns = e & 255u, rm = e >> 8;
+      const uint32_t sn = ns != 255u ? ns : 0u;  // the uninitialised state learns as state 0
+      const float pa = nsp[sn], qb = rmp[rm];
+      const float na = pa + ((float)bit - gmx_logistic_tab(pa, s_tab)) * d.lr;
+      const float nb = qb + ((float)bit - gmx_logistic_tab(qb, s_tab)) * d.lr;
+      const uint32_t e_new = (uint32_t)nsn[2 * sn + bit] | ((uint32_t)rmn[2 * rm + bit] << 8);
+      nsp[sn] = na;
+      rmp[rm] = nb;
+      tab[idx] = (uint16_t)e_new;
+      have_fwd = false;
+      dirty = true;
+    }
+    if (with_forward) {
+      // ---- Indirect::Predict (indirect.cpp:28-46) -------------------------------------------
+      const uint32_t ctx = vc->ctx[slot][ml];
+      const uint32_t bcu = vc->bit_context[slot];
+      idx = ((ctx << 8) + bcu) % d.size;  // indirect.cpp:31-32, 32-bit wrap
+      uint32_t ev;
+      asm volatile("s_waitcnt vmcnt(0)\n\tglobal_load_ushort %0, %1, off\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(ev) : "v"(tab + idx) : "memory");  // behind the entry store of the learn above
+      e = ev;
+      const uint32_t ns = e & 255u, rm = e >> 8;
+      const float qa = nsp[ns], qb = rmp[rm];
+      const bool seen_a = ns != 255u, seen_b = rm != 0u;  // never-seen states leave the slot alone
+      va = seen_a ? qa : va;
+      vb = seen_b ? qb : vb;
+      const uint64_t act_a = __ballot(on && seen_a && qa != 0.f);  // a zero logit is stored, not active
+      const uint64_t act_b = __ballot(on && seen_b && qb != 0.f);
+      have_fwd = true;
+      if (!replay) {
+        if (on) {
+          vr->pred[2 * lane] = va;
+          vr->pred[2 * lane + 1] = vb;
+        }
+        if (lane == 0) {
+          vr->active_a = act_a;
+          vr->active_b = act_b;
+        }
+      }
+    }
+    if (replay) {
+      replay = false;
+      continue;
+    }
+    seen = word;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (lane == 0) __hip_atomic_store(&mr->done_seq, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // leave: what is only in LDS / registers goes back to the bank
+  if (on) {
+    slots[2 * lane] = va;
+    slots[2 * lane + 1] = vb;
+  }
+  __syncthreads();
+  if (dirty)
+    for (int i = lane; i < K * 512; i += 64) gp[i] = ptab[i];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  if (lane == 0) {
+    if (exit_state == GMX_MB_EXIT_STOP)
+      __hip_atomic_store(&mr->done_seq, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mr->state, exit_state, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+extern "C" hipError_t gmx_launch_indirect_session(const GmxIndDev* dv, uint8_t* banks, int stream_idx, GmxIndMbCmd* mc,
+                                                  GmxIndMbReply* mr, unsigned long long idle_ticks,
+                                                  int replay_forward, unsigned lds_bytes, hipStream_t stream) {
+  (void)hipGetLastError();
+  static unsigned allowed = 48u * 1024u;
+  if (lds_bytes > allowed) {
+    hipError_t e = hipFuncSetAttribute((const void*)gmx_indirect_session_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    allowed = lds_bytes;
+  }
+  hipLaunchKernelGGL(gmx_indirect_session_kernel, dim3(1), dim3(64), lds_bytes, stream, dv, banks, stream_idx, mc,
+                     mr, idle_ticks, replay_forward);
+  return hipGetLastError();
+}
+
 // Fill every model's table with "never seen" (nonstationary 255, run map 0) and zero the rest.
 __global__ void gmx_indirect_init_kernel(uint8_t* banks, uint64_t bank_bytes, uint64_t tab_bytes) {
   const uint64_t n16 = tab_bytes / 16;  // tables first, 16-byte granules

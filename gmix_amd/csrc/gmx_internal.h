@@ -139,6 +139,27 @@ struct GmxIndDev {
   GmxIndModelDev m[GMX_IND_MAX_MODELS];
 };
 
+// Mailbox of a per-bit session of the Indirect models (gmx_indirect_session_kernel): same protocol as the
+// mixers' (GmxMbCmd / GmxMbReply above: command word = sequence << 4 | command, answered by the same word
+// in done_seq).
+struct GmxIndMbCmd {       // host -> device: fine-grained device memory behind a large BAR, else pinned host memory
+  uint32_t cmd_seq;        // sequence << 4 | payload slot << 3 | command
+  uint32_t pad0[13];
+  uint32_t bit_context[2]; // ShortTermMemory::bit_context, per payload slot
+  // the models' aliased context variables, read at the Predict call.  Two slots, used alternately: the one
+  // of the forward whose learn is still to come stays intact while the next is written, so a wave
+  // restarted in between can recompute that forward
+  uint32_t ctx[2][GMX_IND_MAX_MODELS];
+};
+struct GmxIndMbReply {     // device -> host: pinned host memory
+  uint32_t done_seq;
+  uint32_t state;          // GMX_MB_RUNNING / GMX_MB_EXIT_*
+  uint32_t pad0[2];
+  uint64_t active_a, active_b;  // bit i: model i's "-indirect" / "-run_map" slot was marked active
+  uint32_t pad1[8];
+  float pred[2 * GMX_IND_MAX_MODELS];  // what the two blackboard slots of model i hold after its Predict
+};
+
 struct GmxIndRunArgs {
   uint8_t* banks;
   const uint32_t* ctx;     // [S][*][k]

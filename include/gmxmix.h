@@ -228,7 +228,9 @@ int gmx_indirect_sync(gmx_indirect* ib);
  * what the blackboard slots of model i hold afterwards ([2i] indirect, [2i+1] run map: a model
  * that stays silent leaves its slot as it was) and whether SetLogitPrediction marked them
  * active (short-term-memory.cpp:193-197).  learn = n_models x Indirect::Learn
- * (indirect.cpp:48-69) with the contexts of the preceding forward. */
+ * (indirect.cpp:48-69) with the contexts of the preceding forward.  Like gmx_bank_forward / gmx_bank_learn these
+ * run through a persistent per-stream session (one mailbox command per bit, the learn travelling with the
+ * next forward) where a session slot is free, else through a kernel launch per call; same floats. */
 int gmx_indirect_forward(gmx_indirect* ib, int stream, const uint32_t* contexts, uint32_t bit_context,
                          float* predictions, uint8_t* active);
 int gmx_indirect_learn(gmx_indirect* ib, int stream, int bit);

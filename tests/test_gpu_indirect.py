@@ -99,6 +99,53 @@ def test_indirect_streams_are_independent_and_per_bit_agrees(gpu, oracle):
     g2.close()
 
 
+@pytest.mark.parametrize("sessions", [1, 0])
+def test_indirect_per_bit_surface_sessions_and_launches(gpu, oracle, sessions):
+    """gmx_indirect_forward / gmx_indirect_learn through the persistent session (one command per bit, the
+    learn riding with the next forward) and through a kernel launch per call: the oracle's floats either way
+    -- with Predicts that are never learned, with the wave leaving on its idle timer between a forward and
+    its learn (it comes back and recomputes the forward from the intact payload slot) and between bits,
+    with a batched run in between (the session writes its logit tables back first), export at the end."""
+    import ctypes as C
+    import time
+    _, z = goldenlib.load("ind_tiny_dense")
+    tabs = (z["ns_next"], z["rm_next"])
+    models = [(256, 0.02), (3, 0.1), (4096, 0.005), (1, 0.5), (65536, 0.02), (1 << 15, 1.0 / 200)]
+    g = gpu.IndirectGroup(models, *tabs, 2)
+    g.L.gmx_debug_indirect_use_sessions.argtypes = [C.c_void_p, C.c_int]
+    assert g.L.gmx_debug_indirect_use_sessions(g.h, sessions) == 0
+    refs = [oracle.IndirectBank(models, *tabs) for _ in range(2)]
+    ctx, bc, bits = oracle.ind_synth(len(models), 420, seed=5, ctx_mod=(40, 3, 900, 0))
+    for t in range(420):
+        s = 1 if 300 <= t < 340 else 0       # a second stream gets a session of its own for a while
+        p, a = g.forward(ctx[t], bc[t], stream=s)
+        pr, ar = refs[s].predict(ctx[t], bc[t])
+        assert np.array_equal(u32(p), u32(pr)) and np.array_equal(a, ar), t
+        if t in (10, 310):                   # the path under test is the one in use
+            assert (g.L.gmx_debug_open_sessions() > 0) == bool(sessions)
+        if t == 50:
+            time.sleep(0.05)                 # > the session's idle timer: the wave leaves holding a forward
+        if t % 9 != 4:
+            g.learn(bits[t], stream=s)
+            refs[s].learn(bits[t])
+        if t == 120:
+            time.sleep(0.05)                 # ... and between bits, with the learn only noted so far
+        if t == 200:                         # batched traffic on the same banks in between
+            b = gpu.IndirectBatch(g, 64)
+            c2, b2, x2 = oracle.ind_synth(len(models), 64, seed=77, ctx_mod=(40, 3, 900, 0))
+            for k in range(2):
+                b.set_records(k, c2, b2, x2)
+                refs[k].run(c2, b2, x2)
+            b.upload()
+            g.run(b)
+            b.download()
+            b.wait()
+            b.close()
+    for k in range(2):
+        assert g.export(k) == refs[k].export(), k
+    g.close()
+
+
 def test_indirect_models_feed_the_mixers_inside_hbm(gpu, oracle):
     """41 stock Indirect models -> 82 of the 90 mixer inputs, written by gmx_indirect_run straight
     into the mixer batch's device records; the other 8 inputs, the mixer contexts come from the
