@@ -116,6 +116,12 @@ def kernel_of(topo, kind, stock_pairs):
     return "gmx_wide_kernel" if kind == "synth3" else "gmx_bank_kernel"
 
 
+def kernels_of(build):
+    """The hash of the mixer kernels' sources inside gmx_build_info() (the whole string if there is none)."""
+    b = build or ""
+    return b.split("kernels ")[-1] if "kernels " in b else b
+
+
 def pmc_traffic(kernel, S, T, ctx_mode, build):
     """HBM traffic per launch from the committed rocprofv3 PMC summary of the same launch shape (the
     counters need separate profiled passes, scripts/gpu_profile.sh; they cannot run inside the timed
@@ -131,7 +137,7 @@ def pmc_traffic(kernel, S, T, ctx_mode, build):
         if pm.get("ctx_mode", ctx_mode) != ctx_mode:
             continue
         return {"traffic": pm["traffic_bytes_per_launch"], "traffic_source": os.path.relpath(f, ROOT),
-                "traffic_stale": pm.get("build") != build}
+                "traffic_stale": kernels_of(pm.get("build")) != kernels_of(build)}
     return {"traffic": None}
 
 

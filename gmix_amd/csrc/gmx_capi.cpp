@@ -265,7 +265,7 @@ extern "C" const char* gmx_strerror(int status) {
 extern "C" const char* gmx_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" const char* gmx_build_info(void) {
-  return "libgmxmix gfx950 (CDNA4) hipcc -O3 -ffp-contract=off; abi 1; src " GMX_SRC_HASH;
+  return "libgmxmix gfx950 (CDNA4) hipcc -O3 -ffp-contract=off; abi 1; src " GMX_SRC_HASH "; kernels " GMX_KERN_HASH;
 }
 
 extern "C" int gmx_device_count(int* count) {
