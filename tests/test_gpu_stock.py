@@ -119,3 +119,36 @@ def test_stock_kernel_forward_only_and_per_bit(gpu, oracle):
         assert beq(out, o_ref[t]) and np.float32(p).view(np.uint32) == p_ref[t].view(np.uint32), t
     assert g.export(0) == before
     g.close()
+
+
+def test_staged_rows_with_every_simd_busy(gpu, oracle):
+    """The staged row path at the stream counts it is chosen for (>= 512: every SIMD of the chip holds a
+    wave, four per CU share an LDS): 1024 streams x 96 bits with new rows every bit and byte-held rows mixed
+    across streams, against the lane-private path on the same records (same floats, same banks) and, for
+    sampled streams, the oracle."""
+    topo = topology.stock(90)
+    S, T = 1024, 96
+    outs = {}
+    for staged in (1, 0):
+        g = gpu.MixerGroup(topo, S)
+        g.L.gmx_debug_stock_staged.argtypes = [C.c_void_p, C.c_int]
+        assert g.L.gmx_debug_stock_staged(g.h, staged) == 0
+        b = gpu.Batch(g, T, outputs=False, mask=False)
+        for rep in range(2):  # the second pass revisits rows the first one wrote back
+            b.fill_synthetic(T, seed=4242, restart=True, ctx_mode=2 if rep == 0 else 0, ctx_mod=1)
+            g.run(b, T)
+        b.download(T)
+        b.wait()
+        outs[staged] = (b.p.copy(), [g.export(s) for s in (0, 1, 511, 777, S - 1)])
+        b.close()
+        g.close()
+    assert np.array_equal(outs[1][0].view(np.uint32), outs[0][0].view(np.uint32))
+    assert outs[1][1] == outs[0][1]
+    GOLD = 0x9E3779B97F4A7C15
+    for k, s in enumerate((0, 1, 511, 777, S - 1)):
+        ob = oracle.Bank(90, topo.skip, topo.mixers)
+        seed = (4242 + s * GOLD) % (1 << 64)
+        ob.run(*oracle.synth(90, 33, T, seed=seed, ctx_mode=2, ctx_mod=1))
+        p_ref, _ = ob.run(*oracle.synth(90, 33, T, seed=seed, ctx_mode=0, ctx_mod=1))
+        assert np.array_equal(outs[1][0][s].view(np.uint32), p_ref.view(np.uint32)), s
+        assert outs[1][1][k] == (ob.export_long(), ob.export_short()), s
