@@ -13,6 +13,7 @@ The same JSON line carries, under "also", the other shapes the north_star names,
 way (barrier, K steps, max over ranks) with its own roofline and one-core reference figure:
   synth3       256 inputs x 24/8/1 mixers (configs[2]'s shape), new gate rows every bit
   stock_held   the reference's own 90 inputs x 24/8/1, gate contexts held through a byte
+  stock_real   the same with the row-change pattern of a real gmix run (the four bit-level contexts move every bit)
   stock_fresh  the same with every gate context new every bit (worst case)
   stock_S1     ONE stream of the reference's shape: what a single compressor sees
 (--no-also leaves them out; --config X makes X the headline workload for profiling.)
@@ -51,10 +52,14 @@ WORKLOADS = {
                    "stock 24/8/1 topology of Predictor::AddMixers, 90 inputs, synthetic records, gate contexts redrawn every 8th bit, forward+update"),
     "stock_fresh": ("stock", 0, 1024, 256, 8_000_000, 400_000,
                     "stock 24/8/1 topology of Predictor::AddMixers, 90 inputs, synthetic records, every gate context new every bit, forward+update"),
+    "stock_real": ("stock", 4, 1024, 256, 8_000_000, 800_000,
+                   "stock 24/8/1 topology of Predictor::AddMixers, 90 inputs, synthetic records with a real run's "
+                   "row-change pattern: all 33 gate contexts redrawn at byte boundaries, the four bit-level ones "
+                   "(2 layer-0, 2 layer-1) every bit, forward+update"),
     "stock_S1": ("stock", 2, 1, 8192, 32_768, 800_000,
                  "ONE stream of the stock 24/8/1 topology (90 inputs), gate contexts redrawn every 8th bit, forward+update"),
 }
-ALSO = ("synth3", "stock_held", "stock_fresh", "stock_S1")
+ALSO = ("synth3", "stock_held", "stock_real", "stock_fresh", "stock_S1")
 
 
 def make_topology(kind):
@@ -221,7 +226,11 @@ def run_workload(name, comm, local_rank, streams=None, bits=None, steps=None, wa
     # rows move when a gate context changes: every bit (ctx-mode 0/1) or every 8th bit (2/3)
     row_bytes = 8 * sum(topo.weight_sizes())
     hold = 8 if ctx_mode >= 2 else 1
-    bytes_per_bit = row_bytes // hold + topo.bytes_per_bit() - row_bytes
+    moved = row_bytes // hold
+    if ctx_mode >= 4:  # ... plus the four bit-level rows on the other seven bits of a byte (oracle/gmx_synth.h)
+        ws = topo.weight_sizes()
+        moved += 7 * 8 * sum(ws[j] for j in (2, 11, 26, 29) if j < len(ws)) // 8
+    bytes_per_bit = moved + topo.bytes_per_bit() - row_bytes
     bytes_per_launch = bytes_per_bit * S * T
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
     kernel = kernel_of(topo, kind, stock_pairs)

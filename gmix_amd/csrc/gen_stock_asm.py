@@ -17,7 +17,7 @@ compiler-generated instruction touches the reserved ranges):
   W(j)  = v[140+j], j = 0..115   the lane's resident row (lane m = mixer m)
   a[140..255]                    the row prefetched lane-private (the 9 quads of a layer-1 / final lane always;
                                  all 29 quads of a layer-0 lane in launches that do not stage rows through LDS)
-  a[44..139]                     24 quads on their way from the write-back image to the stores
+  a[44..175]                     33 quads on their way from the write-back image to the stores (staged launches)
   O0(i) = s[64+i],  i = 0..23    layer-0 outputs;  O1(i) = s[88+i], i = 0..7  layer-1 outputs
 
 Hazards honoured by construction (gfx940/gfx950; the spacing hipcc itself keeps):
@@ -65,8 +65,8 @@ def A4(q):
 
 LLVM_MC = "/opt/rocm/lib/llvm/bin/llvm-mc"
 _DUMMY = {  # operand placeholders -> registers of the right class, for sizing only
-    "sv": "s[10:11]", "mask": "s[12:13]", "seenlo": "s14", "seenhi": "s15", "nm": "s14", "em": "s14", "img": "s15",
-    "sm0": "s16", "p": "v[2:3]", "p0": "v[4:5]", "p1": "v[6:7]", "up2": "v[8:9]", "sc2": "v[8:9]",
+    "sv": "s[10:11]", "mask": "s[12:13]", "seenlo": "s14", "seenhi": "s15", "nm": "s[14:15]", "em": "s[14:15]", "img": "s16",
+    "sm0": "s17", "p": "v[2:3]", "p0": "v[4:5]", "p1": "v[6:7]", "up2": "v[8:9]", "sc2": "v[8:9]",
 }
 
 
@@ -139,7 +139,7 @@ def adopt(first, last):
 
 
 SP = 64        # s64..s71: four rotating SGPR pairs for row addresses (O0/O1 are dead outside forward..update)
-STG = 44       # a44..a139: 24 quads, the write-back's way from the image to the stores
+STG = 44       # a44..a175: 33 quads, the write-back's way from the image to the stores
 PITCH = 528    # bytes between rows of a staging image: 33 quads, odd, so transposed accesses do not conflict
 
 
@@ -148,19 +148,26 @@ def _row_addr(r, lo, hi):
     return [f"v_readlane_b32 s{p}, {lo}, {r}", f"v_readlane_b32 s{p + 1}, {hi}, {r}"]
 
 
-def fetch_l0():
-    """Layer-0 rows of the mixers in %[nm], HBM -> staging image, one coalesced LDS-DMA per row (32
-    lanes x 16 contiguous bytes) instead of 29 lane-private 16-byte loads that touch 24 different
-    lines each.  The row address lives in lane r (%[plo]/%[phi]) and is made scalar two rows ahead of
-    its use (v_readlane -> VMEM address: 5 wait states); an unchanged row issues with exec = 0."""
+def _row_lanes(r):
+    """a layer-0 row is 512 bytes = 32 lanes x 16, a layer-1 / final row 256 bytes = 16 lanes"""
+    return "-1" if r < L0 else "0xffff"
+
+
+def fetch_rows():
+    """The rows of the mixers in %[nm] (64-bit), HBM -> staging image, one coalesced LDS-DMA per row (32 or
+    16 lanes x 16 contiguous bytes) instead of 29 lane-private 16-byte loads that touch as many different
+    lines as there are lanes.  The row address lives in lane r (%[plo]/%[phi]) and is made scalar two rows
+    ahead of its use (v_readlane -> VMEM address: 5 wait states); an unchanged row issues with exec = 0.
+    This is the stream for bits where most rows move (byte boundaries); gmx_stock.hip walks the set bits
+    of %[nm] itself when few do."""
     l = ["s_mov_b64 %[sv], exec", "s_mov_b32 %[sm0], m0", "s_mov_b32 exec_hi, 0"]
     l += _row_addr(0, "%[plo]", "%[phi]") + _row_addr(1, "%[plo]", "%[phi]")
-    for r in range(L0):
-        if r + 2 < L0:
+    for r in range(M):
+        if r + 2 < M:
             l += _row_addr(r + 2, "%[plo]", "%[phi]")
         p = SP + 2 * (r % 4)
-        l.append(f"s_bitcmp1_b32 %[nm], {r}")
-        l.append("s_cselect_b32 exec_lo, -1, 0")
+        l.append(f"s_bitcmp1_b64 %[nm], {r}")
+        l.append(f"s_cselect_b32 exec_lo, {_row_lanes(r)}, 0")
         l.append(f"s_add_u32 m0, %[img], {PITCH * r}")
         l.append("s_nop 0")
         l.append(f"global_load_lds_dwordx4 %[voff], s[{p}:{p + 1}]")
@@ -168,21 +175,21 @@ def fetch_l0():
     return l
 
 
-def evict_l0():
+def evict_rows():
     """... and back: the rows the lanes of %[em] wrote into the write-back image (to_image) leave as one
-    coalesced 512-byte store per row.  All 24 rows of the image are read (into a44..a139: no scalar
-    work, one wait); a row that is not being replaced stores with exec = 0."""
+    coalesced store per row.  All 33 rows of the image are read (into a44..a175: no scalar work, one
+    wait); a row that is not being replaced stores with exec = 0."""
     l = ["s_mov_b64 %[sv], exec"]
-    for r in range(L0):
+    for r in range(M):
         l.append(f"ds_read_b128 a[{STG + 4 * r}:{STG + 4 * r + 3}], %[va] offset:{PITCH * r}")
     l.append("s_mov_b32 exec_hi, 0")
     l += _row_addr(0, "%[plo]", "%[phi]") + _row_addr(1, "%[plo]", "%[phi]")
-    for r in range(L0):
-        if r + 2 < L0:
+    for r in range(M):
+        if r + 2 < M:
             l += _row_addr(r + 2, "%[plo]", "%[phi]")
         p = SP + 2 * (r % 4)
-        l.append(f"s_bitcmp1_b32 %[em], {r}")
-        l.append("s_cselect_b32 exec_lo, -1, 0")
+        l.append(f"s_bitcmp1_b64 %[em], {r}")
+        l.append(f"s_cselect_b32 exec_lo, {_row_lanes(r)}, 0")
         if r == 0:
             l.append("s_waitcnt lgkmcnt(0)")
         l.append(f"global_store_dwordx4 %[voff], a[{STG + 4 * r}:{STG + 4 * r + 3}], s[{p}:{p + 1}]")
@@ -408,9 +415,11 @@ def main():
         # sessions): with the texture path to itself a wave moves its rows faster lane-private than through
         # the images (fewer instructions), with all four SIMDs of every CU doing it the images win
         "GMX_STK_LOAD_B": loads(NQA, NQW), "GMX_STK_STORE_B": stores(NQA, NQW), "GMX_STK_ADOPT_B": adopt(NQA, NQW),
-        # layer-0 rows (24 x 512 bytes): through staging images in LDS, coalesced on the HBM side
-        "GMX_STK_FETCH_L0": fetch_l0(), "GMX_STK_EVICT_L0": evict_l0(),
-        "GMX_STK_TO_IMAGE": to_image(0, NQW), "GMX_STK_FROM_IMAGE": from_image(0, NQW),
+        # launches of many streams: all 33 rows through staging images in LDS, coalesced on the HBM side
+        "GMX_STK_FETCH_ROWS": fetch_rows(), "GMX_STK_EVICT_ROWS": evict_rows(),
+        # lane <-> its image row: part A under the mask of every moving lane, part B under its layer-0 lanes
+        "GMX_STK_TO_IMAGE_A": to_image(0, NQA), "GMX_STK_TO_IMAGE_B": to_image(NQA, NQW),
+        "GMX_STK_FROM_IMAGE_A": from_image(0, NQA), "GMX_STK_FROM_IMAGE_B": from_image(NQA, NQW),
         "GMX_STK_FORWARD": forward(), "GMX_STK_FORWARD_EXACT": forward_exact(),
         "GMX_STK_LOAD_X": load_x_only(), "GMX_STK_OUTPUTS_TO_SGPRS": outputs_to_sgprs(),
         "GMX_STK_UPDATE": update(), "GMX_STK_SHRINK": shrink(), "GMX_STK_ZERO": zero_rows(),

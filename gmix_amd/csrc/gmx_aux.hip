@@ -24,6 +24,9 @@ struct GmxSynthArgs {
   uint32_t ctx_mod, zero_mod;
 };
 
+// bit j set = gate context j is redrawn every bit in ctx_mode 4/5 (GMX_SYNTH_BITLEVEL)
+constexpr uint64_t kSynthBitLevel = (1ull << 2) | (1ull << 11) | (1ull << 26) | (1ull << 29);
+
 __device__ __forceinline__ uint32_t gmx_xs64(uint64_t& s) {
   s ^= s << 13;
   s ^= s >> 7;
@@ -76,6 +79,13 @@ __global__ void __launch_bounds__(64) gmx_synth_kernel(const GmxSynthArgs a) {
     const bool redraw = (a.ctx_mode < 2) || ((tc & 7u) == 0);
     if (redraw) {
       for (int j = 0; j < a.m; ++j) {
+        uint32_t c = gmx_xs64(st);
+        if (a.ctx_mode & 1) c %= cmod;
+        cst[j] = c;
+      }
+    } else if (a.ctx_mode >= 4) {
+      for (int j = 0; j < a.m && j < 64; ++j) {
+        if (!((kSynthBitLevel >> j) & 1)) continue;
         uint32_t c = gmx_xs64(st);
         if (a.ctx_mode & 1) c %= cmod;
         cst[j] = c;

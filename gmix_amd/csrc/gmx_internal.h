@@ -80,8 +80,8 @@ struct GmxRunArgs {
 // while the next one is written (LEARN*_FWD carries both; a wave restarted in between replays the
 // forward from the old slot).
 // LDS of one wave of the stock kernels (gmx_stock.hip): inputs, expf's table, and the two staging images
-// of the 24 layer-0 rows (prefetch, write-back), rows 528 bytes apart
-#define GMX_STK_LDS_BYTES(lds_misc) (((lds_misc) + 256u) * 4u + 2u * 24u * 528u)
+// of the 33 rows (prefetch, write-back), rows 528 bytes apart
+#define GMX_STK_LDS_BYTES(lds_misc) (((lds_misc) + 256u) * 4u + 2u * 33u * 528u)
 
 #define GMX_MB_FORWARD 1u
 #define GMX_MB_LEARN0 2u      // learn, coded bit 0

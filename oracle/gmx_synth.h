@@ -19,6 +19,11 @@
  *                  that does not call SetLogitPrediction -- short-term-memory.cpp:193-197)
  *   ctx_mode 1   : ctx_j = rnd() % ctx_mod
  *   ctx_mode 2/3 : as 0/1 but contexts are only redrawn every 8th bit (byte-boundary contexts)
+ *   ctx_mode 4/5 : as 2/3, and the contexts GMX_SYNTH_BITLEVEL names (j = 2, 11, 26, 29: the
+ *                  positions of the reference predictor's four bit-level gate contexts,
+ *                  predictor.cpp:103-186) are redrawn on every other bit too, in index order --
+ *                  the row-change pattern of a real gmix run: two layer-0 and two layer-1 rows
+ *                  move on every bit, all 33 at a byte boundary
  *   bit_mode 1   : r=rnd(); bit = (x_0 > 0) xor ((r&7)==0) -- a learnable stream, so weights
  *                  grow and outputs leave the neighbourhood of 0 (exercises the squash/clamp)
  */
@@ -28,12 +33,14 @@
 #include <stdint.h>
 
 #define GMX_SYNTH_SEED 0x9E3779B97F4A7C15ull
+/* bit j set = gate context j is bit-level in ctx_mode 4/5 */
+#define GMX_SYNTH_BITLEVEL ((1ull << 2) | (1ull << 11) | (1ull << 26) | (1ull << 29))
 
 typedef struct gmx_synth {
   uint64_t s;        /* xorshift64 state */
   int32_t n;         /* model predictions per bit */
   int32_t m;         /* gate contexts per bit (= mixers) */
-  int32_t ctx_mode;  /* 0..3, see above */
+  int32_t ctx_mode;  /* 0..5, see above */
   uint32_t ctx_mod;  /* modulus for ctx_mode 1/3 */
   uint32_t zero_mod; /* 0 = every model speaks */
   int32_t bit_mode;  /* 0 = random bits, 1 = learnable bits */
@@ -83,6 +90,13 @@ static inline int gmx_synth_step(gmx_synth* g, float* pred, uint8_t* active, uin
   int redraw = (g->ctx_mode < 2) || ((g->t & 7) == 0);
   if (redraw) {
     for (int j = 0; j < g->m; ++j) {
+      uint32_t c = gmx_synth_rnd(g);
+      if (g->ctx_mode & 1) c %= g->ctx_mod;
+      ctx[j] = c;
+    }
+  } else if (g->ctx_mode >= 4) {
+    for (int j = 0; j < g->m && j < 64; ++j) {
+      if (!((GMX_SYNTH_BITLEVEL >> j) & 1)) continue;
       uint32_t c = gmx_synth_rnd(g);
       if (g->ctx_mode & 1) c %= g->ctx_mod;
       ctx[j] = c;

@@ -27,7 +27,7 @@ def test_bench_line_carries_the_contract(gpu):
     assert d["unit"] == "bits/s" and d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "configs[1]" in d["config"]["workload"] and "model" not in d["config"]
-    assert set(d["also"]) == {"synth3", "stock_held", "stock_fresh", "stock_S1"}
+    assert set(d["also"]) == {"synth3", "stock_held", "stock_real", "stock_fresh", "stock_S1"}
     for name, e in [("headline", d)] + list(d["also"].items()):
         assert "error" not in e, (name, e)
         ro = e["roofline"]

@@ -191,13 +191,16 @@ def test_export_import_copy_roundtrip(gpu, oracle):
     g2.close()
 
 
-def test_device_synth_fill_matches_host_generator(gpu, oracle):
+@pytest.mark.parametrize("kw", [dict(ctx_mode=3, ctx_mod=17, zero_mod=6, bit_mode=1),
+                                dict(ctx_mode=5, ctx_mod=300, zero_mod=6, bit_mode=1),
+                                dict(ctx_mode=4, bit_mode=1)],
+                         ids=["byte_held_mod", "bitlevel_mod", "bitlevel"])
+def test_device_synth_fill_matches_host_generator(gpu, oracle, kw):
     """The on-device record generator is oracle/gmx_synth.h restated: same stream per seed."""
-    topo = topology.synth3(90, table0=1 << 8)
+    topo = topology.stock(90) if kw["ctx_mode"] == 4 else topology.synth3(90, table0=1 << 8)
     S, T = 5, 400
     g = gpu.MixerGroup(topo, S)
     b = gpu.Batch(g, T, outputs=True, mask=True)
-    kw = dict(ctx_mode=3, ctx_mod=17, zero_mod=6, bit_mode=1)
     b.fill_synthetic(200, seed=12345, restart=True, **kw)
     g.run(b, 200)
     b.download(200)

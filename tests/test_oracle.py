@@ -116,3 +116,23 @@ def test_coder_restatement(oracle):
     u = oracle.encode(bits, np.full(20000, 0.5, np.float32))
     assert abs(len(u) - 2500) <= 3
     assert oracle.lib().gmxo_discretize(np.float32(0.5)) == 32768
+
+
+def test_synth_bitlevel_context_mode(oracle):
+    """ctx_mode 4/5 of oracle/gmx_synth.h: every gate context moves at a byte boundary, only the four
+    bit-level ones (2, 11, 26, 29 -- the reference predictor's, predictor.cpp:103-186) in between."""
+    T = 400
+    _, _, ctx, _ = oracle.synth(90, 33, T, seed=3, ctx_mode=4)
+    _, _, ctx5, _ = oracle.synth(90, 33, T, seed=3, ctx_mode=5, ctx_mod=1000)
+    level = [2, 11, 26, 29]
+    held = [j for j in range(33) if j not in level]
+    for t in range(1, T):
+        if t % 8:
+            assert (ctx[t, held] == ctx[t - 1, held]).all() and (ctx5[t, held] == ctx5[t - 1, held]).all()
+            assert (ctx[t, level] != ctx[t - 1, level]).all()
+        else:
+            assert (ctx[t] != ctx[t - 1]).sum() >= 32
+    assert ctx5.max() < 1000 and ctx.max() >= 1 << 24
+    # modes 2/3 are untouched by the extension: byte-held everywhere
+    _, _, ctx2, _ = oracle.synth(90, 33, 64, seed=3, ctx_mode=2)
+    assert all((ctx2[t] == ctx2[t - 1]).all() for t in range(1, 64) if t % 8)
