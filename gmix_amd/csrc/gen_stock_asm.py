@@ -65,7 +65,7 @@ def A4(q):
 
 LLVM_MC = "/opt/rocm/lib/llvm/bin/llvm-mc"
 _DUMMY = {  # operand placeholders -> registers of the right class, for sizing only
-    "sv": "s[10:11]", "mask": "s[12:13]", "seenlo": "s14", "seenhi": "s15", "nm": "s[14:15]", "em": "s[14:15]", "img": "s16",
+    "sv": "s[10:11]", "mask": "s[12:13]", "seenlo": "s14", "seenhi": "s15", "nm": "s[14:15]", "em": "s[14:15]", "m": "s[14:15]", "img": "s16",
     "sm0": "s17", "p": "v[2:3]", "p0": "v[4:5]", "p1": "v[6:7]", "up2": "v[8:9]", "sc2": "v[8:9]",
 }
 
@@ -153,7 +153,7 @@ def _row_lanes(r):
     return "-1" if r < L0 else "0xffff"
 
 
-def fetch_rows():
+def fetch_rows(NR=M):
     """The rows of the mixers in %[nm] (64-bit), HBM -> staging image, one coalesced LDS-DMA per row (32 or
     16 lanes x 16 contiguous bytes) instead of 29 lane-private 16-byte loads that touch as many different
     lines as there are lanes.  The row address lives in lane r (%[plo]/%[phi]) and is made scalar two rows
@@ -162,8 +162,8 @@ def fetch_rows():
     of %[nm] itself when few do."""
     l = ["s_mov_b64 %[sv], exec", "s_mov_b32 %[sm0], m0", "s_mov_b32 exec_hi, 0"]
     l += _row_addr(0, "%[plo]", "%[phi]") + _row_addr(1, "%[plo]", "%[phi]")
-    for r in range(M):
-        if r + 2 < M:
+    for r in range(NR):
+        if r + 2 < NR:
             l += _row_addr(r + 2, "%[plo]", "%[phi]")
         p = SP + 2 * (r % 4)
         l.append(f"s_bitcmp1_b64 %[nm], {r}")
@@ -175,17 +175,37 @@ def fetch_rows():
     return l
 
 
-def evict_rows():
+def fetch_sparse():
+    """The same for a few rows: a loop over the set bits of %[m] (64-bit, consumed), 11 instructions a row.
+    s64..s68 are free here (O0 is dead outside forward..update).  The six scalar instructions between the
+    second v_readlane and the LDS-DMA are its wait states (v_readlane -> VMEM address: 5; m0 -> LDS-DMA: 1)."""
+    return [f"s_mov_b32 s{SP + 3}, 0xffff", "s_mov_b64 %[sv], exec", "s_mov_b32 %[sm0], m0", "s_mov_b32 exec_hi, 0",
+            f"s_movk_i32 s{SP + 4}, {PITCH}", "s_nop 0",  # the loop starts at 4 mod 8: nothing in it straddles
+            f"1: s_ff1_i32_b64 s{SP + 2}, %[m]",
+            f"v_readlane_b32 s{SP}, %[plo], s{SP + 2}",
+            f"v_readlane_b32 s{SP + 1}, %[phi], s{SP + 2}",
+            f"s_bitset0_b64 %[m], s{SP + 2}",
+            f"s_cmp_lt_u32 s{SP + 2}, {L0}",
+            f"s_cselect_b32 exec_lo, -1, s{SP + 3}",
+            f"s_mul_i32 s{SP + 2}, s{SP + 2}, s{SP + 4}",
+            f"s_add_u32 m0, %[img], s{SP + 2}",
+            "s_cmp_lg_u64 %[m], 0",
+            f"global_load_lds_dwordx4 %[voff], s[{SP}:{SP + 1}]",
+            "s_cbranch_scc1 1b",
+            "s_mov_b32 m0, %[sm0]", "s_mov_b64 exec, %[sv]"]
+
+
+def evict_rows(NR=M):
     """... and back: the rows the lanes of %[em] wrote into the write-back image (to_image) leave as one
     coalesced store per row.  All 33 rows of the image are read (into a44..a175: no scalar work, one
     wait); a row that is not being replaced stores with exec = 0."""
     l = ["s_mov_b64 %[sv], exec"]
-    for r in range(M):
+    for r in range(NR):
         l.append(f"ds_read_b128 a[{STG + 4 * r}:{STG + 4 * r + 3}], %[va] offset:{PITCH * r}")
     l.append("s_mov_b32 exec_hi, 0")
     l += _row_addr(0, "%[plo]", "%[phi]") + _row_addr(1, "%[plo]", "%[phi]")
-    for r in range(M):
-        if r + 2 < M:
+    for r in range(NR):
+        if r + 2 < NR:
             l += _row_addr(r + 2, "%[plo]", "%[phi]")
         p = SP + 2 * (r % 4)
         l.append(f"s_bitcmp1_b64 %[em], {r}")
@@ -415,8 +435,9 @@ def main():
         # sessions): with the texture path to itself a wave moves its rows faster lane-private than through
         # the images (fewer instructions), with all four SIMDs of every CU doing it the images win
         "GMX_STK_LOAD_B": loads(NQA, NQW), "GMX_STK_STORE_B": stores(NQA, NQW), "GMX_STK_ADOPT_B": adopt(NQA, NQW),
-        # launches of many streams: all 33 rows through staging images in LDS, coalesced on the HBM side
-        "GMX_STK_FETCH_ROWS": fetch_rows(), "GMX_STK_EVICT_ROWS": evict_rows(),
+        # launches of many streams: rows through staging images in LDS, coalesced on the HBM side -- with
+        # fixed 33-row streams when most of them move, a few in a loop (fetch_sparse)
+        "GMX_STK_FETCH_ROWS": fetch_rows(), "GMX_STK_FETCH_SPARSE": fetch_sparse(), "GMX_STK_EVICT_ROWS": evict_rows(),
         # lane <-> its image row: part A under the mask of every moving lane, part B under its layer-0 lanes
         "GMX_STK_TO_IMAGE_A": to_image(0, NQA), "GMX_STK_TO_IMAGE_B": to_image(NQA, NQW),
         "GMX_STK_FROM_IMAGE_A": from_image(0, NQA), "GMX_STK_FROM_IMAGE_B": from_image(NQA, NQW),

@@ -11,7 +11,7 @@
 #define REP(n, ins) ".set o,0\n\t.rept " #n "\n\t" ins "\n\t.set o,o+16\n\t.endr\n\t"
 #define REPP(n, ins) ".set o,0\n\t.rept " #n "\n\t" ins "\n\t.set o,o+528\n\t.endr\n\t"
 
-constexpr int kTests = 16;
+constexpr int kTests = 22;
 
 #define TIMED(id, setup_exec, body, wait)                                                     \
   {                                                                                           \
@@ -24,7 +24,7 @@ constexpr int kTests = 16;
                  : [sv] "=&s"(sv), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2)           \
                  : [p] "v"(prow), [pc] "s"(pbase), [voff] "v"(lane16), [l] "v"(lrow), [lc] "v"(lco), [m2] "s"(m2), \
                    [m33] "s"(m33), [m32] "s"(m32), [m24] "s"(m24), [z] "s"(0ull)             \
-                 : "memory", "v40", "v41", "v42", "v43", "a40", "a41", "a42", "a43");         \
+                 : "memory", "v40", "v41", "v42", "v43", "a40", "a41", "a42", "a43", "v36", "v37", "v38", "v39");         \
     if (threadIdx.x == 0) {                                                                   \
       out[(blockIdx.x * kTests + id) * 2 + 0] = (uint32_t)(t1 - t0);                          \
       out[(blockIdx.x * kTests + id) * 2 + 1] = (uint32_t)(t2 - t0);                          \
@@ -69,6 +69,16 @@ __global__ void __launch_bounds__(64) ubench(uint8_t* rows, uint32_t* out, int r
   TIMED(14, "s_mov_b64 exec, %[m32]\n\ts_mov_b32 m0, 0\n\t", "global_load_lds_dwordx4 %[voff], %[pc] offset:512\n\t", "s_waitcnt vmcnt(0)\n\t")
   // 15: 29 s_nop 0 (the scale: 1 instruction / issue slot)
   TIMED(15, "", ".rept 29\n\ts_nop 0\n\t.endr\n\t", "")
+  // 16..19: can VALU work hide the LDS write path?  232 packed multiplies alone / with a ds_write_b128 after every 8th,
+  // 116 alone / with one after every 4th
+  TIMED(16, "", ".rept 232\n\tv_pk_mul_f32 v[40:41], v[42:43], v[42:43]\n\t.endr\n\t", "")
+  TIMED(17, "", ".set o,0\n\t.rept 29\n\t.rept 8\n\tv_pk_mul_f32 v[40:41], v[42:43], v[42:43]\n\t.endr\n\tds_write_b128 %[l], v[36:39] offset:o\n\t.set o,o+16\n\t.endr\n\t", "")
+  TIMED(18, "", ".rept 116\n\tv_pk_mul_f32 v[40:41], v[42:43], v[42:43]\n\t.endr\n\t", "")
+  TIMED(19, "", ".set o,0\n\t.rept 29\n\t.rept 4\n\tv_pk_mul_f32 v[40:41], v[42:43], v[42:43]\n\t.endr\n\tds_write_b128 %[l], v[36:39] offset:o\n\t.set o,o+16\n\t.endr\n\t", "")
+  // 20/21: the same question for ds_read_b128 (transposed, 24 lanes) behind 4 multiplies each, and for 29 lane-private
+  // stores of 2 lanes behind 8 multiplies each
+  TIMED(20, "s_mov_b64 exec, %[m24]\n\t", ".set o,0\n\t.rept 29\n\t.rept 4\n\tv_pk_mul_f32 v[40:41], v[42:43], v[42:43]\n\t.endr\n\tds_read_b128 v[36:39], %[l] offset:o\n\t.set o,o+16\n\t.endr\n\t", "")
+  TIMED(21, "", ".set o,0\n\t.rept 29\n\t.rept 8\n\tv_pk_mul_f32 v[40:41], v[42:43], v[42:43]\n\t.endr\n\ts_mov_b64 exec, %[m2]\n\tglobal_store_dwordx4 %[p], v[36:39], off offset:o\n\ts_mov_b64 exec, %[m33]\n\t.set o,o+16\n\t.endr\n\t", "s_waitcnt vmcnt(0)\n\t")
 }
 
 int main(int argc, char** argv) {
@@ -87,7 +97,9 @@ int main(int argc, char** argv) {
                                "29 transposed ds_read_b128, 24 lanes", "  ... 2 lanes",
                                "29 transposed ds_write_b128, 24 lanes", "  ... 2 lanes",
                                "24 coalesced ds_read_b128 -> AGPR, 32 lanes", "116 v_accvgpr_read_b32",
-                               "1 LDS-DMA row + wait", "29 s_nop 0"};
+                               "1 LDS-DMA row + wait", "29 s_nop 0", "232 v_pk_mul_f32", "  ... + 29 ds_write_b128, one per 8",
+                               "116 v_pk_mul_f32", "  ... + 29 ds_write_b128, one per 4", "116 v_pk_mul_f32 + 29 ds_read_b128, one per 4",
+                               "232 v_pk_mul_f32 + 29 2-lane global_store_dwordx4"};
   for (int rep = 0; rep < 3; ++rep) {
     hipLaunchKernelGGL(ubench, dim3(blocks), dim3(64), 40960, 0, rows, out, rep);
     if (hipDeviceSynchronize() != hipSuccess) return 2;
