@@ -1,5 +1,5 @@
 // gmx_indirect.hip -- the reference's Indirect models (models/indirect.cpp:28-69) for T bits of
-// many streams: one wave per stream, lane k = model k.
+// many streams: two waves per stream (one per state of a model), lane k = model k.
 //
 // Per bit a model reads ONE byte pair -- its two states for the table index
 // ((context << 8) + bit_context) % size -- maps each state to a logit through a 256-entry table,
@@ -51,12 +51,36 @@ __device__ __forceinline__ void ind_ld8(uint32_t& d, const uint8_t* p) {
   asm volatile("global_load_ubyte %0, %1, off" : "=v"(d) : "v"(p) : "memory");
 }
 
+// Phase profile (-DGMX_IND_PROF, `make -C gmix_amd/csrc prof`): s_memtime ticks wave 0 of block 0 spends in
+// the stages of a full block, summed; read with gmx_indirect_prof_read.
+#ifdef GMX_IND_PROF
+__device__ unsigned long long gmx_ind_prof[8];
+#define IND_STAMP(i)                                             \
+  do {                                                           \
+    if (prof_on) {                                               \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+      prof_acc[i] += now_ - tprev_;                              \
+      tprev_ = now_;                                             \
+    }                                                            \
+  } while (0)
+#else
+#define IND_STAMP(i)
+#endif
+
 // OUT: write {predictions, active} records; MX: write into a mixer batch; LEARN: Indirect::Learn.
+//
+// Two waves per stream.  A model is two independent predictors that share nothing but the table index:
+// the nonstationary state (low byte of the entry, logits nsp, next-state table ns_next, blackboard slot
+// "-indirect") and the run-map state (high byte, rmp, rm_next, slot "-run_map").  With one wave per SIMD
+// the loop is bound by the instructions the wave issues per bit, most of them the two Sigmoid::Logistic;
+// wave 0 of the block takes the first half, wave 1 the second, each reads and writes only its own byte of
+// an entry, its own logit table and its own output slots -- they never wait for each other.
 template <bool OUT, bool MX, bool LEARN>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(128)
 gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: nonstationary, 1: run map
   const int K = dv->k;
   const int s = a.stream_base + (int)blockIdx.x;
   const int rec = a.rec_base + (int)blockIdx.x;
@@ -64,186 +88,301 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
   if (T == 0) return;
   uint8_t* const bank = a.banks + (uint64_t)s * dv->bank_bytes;
 
-  // LDS: [k][512] logits | exp2 table (32 x u64) | ns_next[512] | rm_next[512] | mask words
+  // LDS: [k][512] logits | exp2 table (32 x u64) | ns_next[512] | rm_next[512] | mask words [2][8]
   float* const ptab = lds;
   uint64_t* const s_tab = (uint64_t*)(lds + (size_t)K * 512);
   uint8_t* const nsn = (uint8_t*)(s_tab + 32);
   uint8_t* const rmn = nsn + 512;
-  uint32_t* const mw = (uint32_t*)(rmn + 512);
+  uint32_t* const mw = (uint32_t*)(rmn + 512) + 8 * half;
   float* const gp = (float*)(bank + dv->pred_off);
-  for (int i = lane; i < K * 512; i += 64) ptab[i] = gp[i];
-  if (lane < 32) s_tab[lane] = gmx_exp2f_tab[lane];
-  for (int i = lane; i < 512; i += 64) {
+  for (int i = threadIdx.x; i < K * 512; i += 128) ptab[i] = gp[i];
+  if (threadIdx.x < 32) s_tab[threadIdx.x] = gmx_exp2f_tab[threadIdx.x];
+  for (int i = threadIdx.x; i < 512; i += 128) {
     nsn[i] = dv->ns_next[i];
     rmn[i] = dv->rm_next[i];
   }
   __syncthreads();
 
   const bool on = lane < K;
-  // idle lanes mirror model 0: same values to the same addresses, so the loop needs no exec
-  // masking at all (a divergent region around the stores also makes hipcc drain vmcnt per bit)
   const int ml = on ? lane : 0;
   const GmxIndModelDev d = dv->m[ml];
-  uint16_t* const tab = (uint16_t*)(bank + d.tab_off);
+  uint8_t* const tab = bank + d.tab_off + half;  // this half's byte of entry i: tab[2 * i]
   float* const slots = (float*)(bank + dv->slots_off);
-  float va = slots[2 * ml], vb = slots[2 * ml + 1];
-  float* const nsp = ptab + (size_t)ml * 512;
-  float* const rmp = nsp + 256;
+  float val = slots[2 * ml + half];
+  float* const lp = ptab + (size_t)ml * 512 + 256 * half;  // this half's 256 logits
+  const uint8_t* const nextp = half ? rmn : nsn;
+  const int slot = half ? d.slot_b : d.slot_a;
+  const uint32_t unseen = half ? 0u : 255u;  // run-map state 0 / nonstationary state 255: never seen
 
   const uint64_t RS = a.rec_stride;
   const uint32_t* const ctx_s = a.ctx + (uint64_t)rec * RS * K;
   const uint32_t* const bc_s = a.bc + (uint64_t)rec * RS;
   const uint8_t* const bits_s = a.bits + (uint64_t)rec * RS;
-  float* const po = OUT ? a.pred_out + (uint64_t)rec * RS * 2 * K : nullptr;
-  uint8_t* const ao = OUT ? a.act_out + (uint64_t)rec * RS * 2 * K : nullptr;
-  float* const mxp = MX ? a.mx_pred + (uint64_t)rec * a.mx_rec_stride * a.mx_n_pad : nullptr;
+  float* const po = OUT ? a.pred_out + (uint64_t)rec * RS * 2 * K + 2 * ml + half : nullptr;
+  uint8_t* const ao = OUT ? a.act_out + (uint64_t)rec * RS * 2 * K + 2 * ml + half : nullptr;
+  float* const mxp = MX ? a.mx_pred + (uint64_t)rec * a.mx_rec_stride * a.mx_n_pad + slot : nullptr;
   uint32_t* const mxm = MX ? a.mx_mask + (uint64_t)rec * a.mx_rec_stride * a.mx_mask_words : nullptr;
   uint8_t* const mxb = MX ? a.mx_bits + (uint64_t)rec * a.mx_rec_stride : nullptr;
-  const int MW = a.mx_mask_words;
-  // bits of the attached mask that belong to the Indirect models (cleared and rewritten per bit)
+  const int MW = a.mx_mask_words;  // <= 8 (the launcher checks)
+  // bits of the attached mask that belong to this half's slots (cleared and rewritten per bit).  The mask
+  // words are composed in LDS by the wave alone: LDS keeps one wave's accesses in order, no barrier.
   uint32_t own = 0;
   if (MX) {
     if (lane < MW) mw[lane] = 0;
-    __syncthreads();
-    if (on) {
-      atomicOr(&mw[d.slot_a >> 5], 1u << (d.slot_a & 31));
-      atomicOr(&mw[d.slot_b >> 5], 1u << (d.slot_b & 31));
-    }
-    __syncthreads();
+    if (on) atomicOr(&mw[slot >> 5], 1u << (slot & 31));
     if (lane < MW) own = mw[lane];
-    __syncthreads();
   }
 
-  // Bits are processed in blocks of D.  The table indices of a block depend on the records only,
-  // so its D entries are fetched together -- one memory latency per block instead of one per
-  // bit -- behind the records of the next block; an entry that the block itself rewrites
-  // before using it again is patched from registers.  The body is branch-free per lane
-  // (selects): with one wave per stream every exec-mask detour costs.  (Fetching block b+1's
-  // entries during block b was tried: what it hides is less than what patching across blocks
-  // costs -- the loop is bound by its dependent LDS/logistic chain, not by the fetch.)
-  constexpr int D = 8;
-  uint32_t prev_ctx = 0, base = 0;
-  bool have_base = false;
-  // ((context << 8) + bit_context) % size (indirect.cpp:31-32, 32-bit wrap).  A model's context
-  // changes once per byte, so the residue of (context << 8) is kept.
-  auto index_of = [&](uint32_t ctx, uint32_t bcu) -> uint32_t {
-    const bool moved = !have_base || ctx != prev_ctx;
-    if (__ballot(moved)) {  // wave-uniform
-      const uint32_t nb = (ctx << 8) % d.size;
-      base = moved ? nb : base;
-      prev_ctx = ctx;
-      have_base = true;
-    }
-    if (bcu < 256u) {  // always true for the reference's bit_context
-      const uint32_t ix = base + bcu;
-      return ix >= d.size ? ix - d.size : ix;
-    }
-    return ((ctx << 8) + bcu) % d.size;
-  };
-  auto load_records = [&](uint32_t* c, uint32_t* bcv, uint32_t* bv, uint64_t t_first) {
-    if (t_first + D <= T) {
-      ind_block_records<0, D>(c, bcv, bv, ctx_s + t_first * K + ml, (uint32_t)K * 4u, bc_s + t_first,
-                              bits_s + t_first);
-    } else {
-#pragma unroll
-      for (int j = 0; j < D; ++j) {  // the last blocks: clamped (values past T are not used)
-        uint64_t t = t_first + j;
-        t = t < T ? t : T - 1;
-        ind_ld32(c[j], ctx_s + t * K + ml);
-        ind_ld32(bcv[j], bc_s + t);
-        ind_ld8o<0>(bv[j], bits_s + t);
+  // The lanes without a model sit the loop out: a vector-memory instruction whose lanes go to different
+  // lines costs the wave time per active lane.
+  if (on) {
+#ifdef GMX_IND_PROF
+    const bool prof_on = blockIdx.x == 0 && threadIdx.x == 0;
+    unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
+    // Bits are processed in blocks of D = 8.  The table indices of a block depend on the records only, so
+    // its D entries are fetched while the block before it is processed, behind the records of the block
+    // after it: no memory latency is left in the loop.  What the block in between writes into an entry the
+    // fetched block uses is patched in from registers.
+    //
+    // The reference's own records are "byte-shaped": a block is one byte -- one context per model, the
+    // bit_context + 1 of bit j j+1 bits long.  Then the D entries of a block are distinct, entry j of a block can
+    // only coincide with entry j of the block before it (same context, same bit_context) unless the index
+    // ranges of two different contexts overlap (`near`), the index is an add and a wrap, and nothing in a
+    // bit's code depends on lane-uniform branches.  Any other shape of records takes the general code: the
+    // residue per bit, entries that repeat inside a block patched pairwise, the next block's entries fetched
+    // again behind this block's stores.  With one wave per SIMD the loop is bound by the instructions it
+    // issues: the shaped path is written to need few.
+    constexpr int D = 8;
+    struct Recs {
+      uint32_t ctx[D], bc[D], bit[D];
+    };
+    struct Block {
+      uint32_t idx[D], e[D];
+      bool shaped;  // wave-uniform: byte-shaped for every model
+      bool clean;   // wave-uniform: shaped, and no model's index range overlaps that of the block before
+    };
+    uint32_t prev_ctx = 0, base = 0;
+    bool have_base = false;
+    // ((context << 8) + bit_context) % size (indirect.cpp:31-32, 32-bit wrap), any records.  A model's
+    // context changes once per byte, so the residue of (context << 8) is kept.
+    auto index_of = [&](uint32_t ctx, uint32_t bcu) -> uint32_t {
+      const bool moved = !have_base || ctx != prev_ctx;
+      if (__ballot(moved)) {  // wave-uniform
+        const uint32_t nb = (ctx << 8) % d.size;
+        base = moved ? nb : base;
+        prev_ctx = ctx;
+        have_base = true;
       }
-    }
-  };
-  uint32_t ctx_r[D], bc_r[D], bit_r[D];
-  load_records(ctx_r, bc_r, bit_r, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (bcu < 256u) {
+        const uint32_t ix = base + bcu;
+        return ix >= d.size ? ix - d.size : ix;
+      }
+      return ((ctx << 8) + bcu) % d.size;
+    };
+    auto load_records = [&](Recs& r, uint64_t t_first) {
+      if (t_first + D <= T) {
+        ind_block_records<0, D>(r.ctx, r.bc, r.bit, ctx_s + t_first * K + ml, (uint32_t)K * 4u, bc_s + t_first,
+                                bits_s + t_first);
+      } else {
 #pragma unroll
-  for (int j = 0; j < D; ++j) asm volatile("" : "+v"(ctx_r[j]), "+v"(bc_r[j]), "+v"(bit_r[j]));
+        for (int j = 0; j < D; ++j) {  // the last blocks: clamped (values past T are not used)
+          uint64_t t = t_first + j;
+          t = t < T ? t : T - 1;
+          ind_ld32(r.ctx[j], ctx_s + t * K + ml);
+          ind_ld32(r.bc[j], bc_s + t);
+          ind_ld8o<0>(r.bit[j], bits_s + t);
+        }
+      }
+    };
+    auto pin_records = [&](Recs& r) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) asm volatile("" : "+v"(r.ctx[j]), "+v"(r.bc[j]), "+v"(r.bit[j]));
+    };
+    auto pin_entries = [&](Block& blk) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) asm volatile("" : "+v"(blk.e[j]));
+    };
+    // indices of a block and the loads of its entries (this wave's byte of each)
+    auto block_indices = [&](Block& blk, const Recs& r) {
+      uint32_t odd = 0;  // branch-free: any bit set = not byte-shaped
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        odd |= ((r.bc[j] + 1u) >> j) ^ 1u;  // bit_context = recent_bits - 1 (basic-contexts.cpp:33)
+        if (j > 0) odd |= r.ctx[j] ^ r.ctx[0];
+      }
+      blk.shaped = __ballot(odd != 0u) == 0;
+      const uint32_t base_before = base;
+      const bool had = have_base;
+      if (blk.shaped) {
+        const bool moved = !have_base || r.ctx[0] != prev_ctx;
+        if (__ballot(moved)) {
+          const uint32_t nb = (r.ctx[0] << 8) % d.size;
+          base = moved ? nb : base;
+        }
+        prev_ctx = r.ctx[0];
+        have_base = true;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const uint32_t ix = base + r.bc[j];
+          blk.idx[j] = ix >= d.size ? ix - d.size : ix;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j) blk.idx[j] = index_of(r.ctx[j], __builtin_amdgcn_readfirstlane(r.bc[j]));
+      }
+      IND_STAMP(5);
+#pragma unroll
+      for (int j = 0; j < D; ++j) ind_ld8(blk.e[j], tab + 2ull * blk.idx[j]);
+      IND_STAMP(6);
+      const uint32_t dd = base >= base_before ? base - base_before : base_before - base;
+      const bool near = had && dd != 0u && (dd < 256u || d.size - dd < 256u);
+      blk.clean = blk.shaped && __ballot(near) == 0;
+    };
+    // stores a full block issues behind the next block's entry loads (vector memory returns in order)
+    constexpr int kStoresPerBlock = D * ((OUT ? 2 : 0) + (MX ? 1 : 0) + (LEARN ? 1 : 0));
 
-  for (uint64_t t0 = 0; t0 < T; t0 += D) {
-    // records of the next block first: vector memory returns in order, so once this block's
-    // entries (issued behind them) are there, nothing is left to wait for while the bits run
-    uint32_t ctx_n[D], bc_n[D], bit_n[D], idx[D], e[D];
-    load_records(ctx_n, bc_n, bit_n, t0 + D);
-    // Inside one byte (one context, bit_context growing) the D indices are distinct: the usual
-    // case, blocks being bytes.  Otherwise an entry may come twice and is patched below.
-    bool plain = true;
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const uint32_t bcu = __builtin_amdgcn_readfirstlane(bc_r[j]);
-      idx[j] = index_of(ctx_r[j], bcu);
-      ind_ld16(e[j], tab + idx[j]);
-      plain = plain && bcu < 256u;
-      if (j > 0) plain = plain && ctx_r[j] == ctx_r[0] && bcu > __builtin_amdgcn_readfirstlane(bc_r[j - 1]);
-    }
-    const bool patch = __ballot(!plain) != 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < D; ++j)  // pins the loaded registers behind the wait
-      asm volatile("" : "+v"(e[j]), "+v"(ctx_n[j]), "+v"(bc_n[j]), "+v"(bit_n[j]));
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const uint64_t t = t0 + j;
-      if (t >= T) break;
-      const int bit = (int)__builtin_amdgcn_readfirstlane(bit_r[j]);
+    // running output positions (bit t): one add per bit instead of a 64-bit multiply
+    float* po_t = po;
+    uint8_t* ao_t = ao;
+    float* mxp_t = mxp;
+    uint32_t* mxm_t = MX ? mxm + lane : nullptr;
+    uint8_t* mxb_t = mxb;
+    const uint32_t K2 = 2u * (uint32_t)K;
+    const bool bit_writer = half == 0 && lane == 0;
+
+    // one bit of block `cur`: Indirect::Predict, the outputs, Indirect::Learn; e_new = the entry afterwards
+    auto do_bit = [&](Block& cur, int j, uint32_t bit, uint32_t& e_new) {
       // ---- Indirect::Predict (indirect.cpp:28-46) ------------------------------------------
-      const uint32_t ns = e[j] & 255u, rm = e[j] >> 8;
-      const float qa = nsp[ns], qb = rmp[rm];
-      const bool seen_a = ns != 255u, seen_b = rm != 0u;  // never-seen states leave the slot alone
-      va = seen_a ? qa : va;
-      vb = seen_b ? qb : vb;
-      const bool act_a = seen_a && qa != 0.f;  // SetLogitPrediction: a zero logit is stored, not active
-      const bool act_b = seen_b && qb != 0.f;
+      const uint32_t st = cur.e[j];
+      const float q = lp[st];
+      const float p0 = lp[0];          // what an uninitialised nonstationary state learns at (read beside q, not behind it)
+      const bool seen = st != unseen;  // a never-seen state leaves the slot alone
+      val = seen ? q : val;
+      const bool act = seen && q != 0.f;  // SetLogitPrediction: a zero logit is stored, not active
       if (OUT) {
-        *(float2*)(po + t * 2 * K + 2 * ml) = make_float2(va, vb);
-        *(uchar2*)(ao + t * 2 * K + 2 * ml) = make_uchar2(act_a, act_b);
+        *po_t = val;
+        *ao_t = (uint8_t)act;
+        po_t += K2;
+        ao_t += K2;
       }
       if (MX) {
-        mxp[t * a.mx_n_pad + d.slot_a] = va;
-        mxp[t * a.mx_n_pad + d.slot_b] = vb;
+        *mxp_t = val;
+        mxp_t += a.mx_n_pad;
         if (lane < MW) mw[lane] = 0;
-        __syncthreads();
-        if (act_a) atomicOr(&mw[d.slot_a >> 5], 1u << (d.slot_a & 31));
-        if (act_b) atomicOr(&mw[d.slot_b >> 5], 1u << (d.slot_b & 31));
-        __syncthreads();
+        if (act) atomicOr(&mw[slot >> 5], 1u << (slot & 31));
         if (lane < MW) {
-          uint32_t* wp = mxm + t * MW + lane;
-          *wp = (*wp & ~own) | mw[lane];
+          // the other wave rewrites its own bits of the same words: two atomics whose order does not matter
+          atomicAnd(mxm_t, ~own);
+          atomicOr(mxm_t, mw[lane]);
         }
-        if (lane == 0) mxb[t] = (uint8_t)bit;
-        __syncthreads();
+        mxm_t += MW;
+        if (bit_writer) *mxb_t = (uint8_t)bit;
+        ++mxb_t;
       }
       // ---- Indirect::Learn (indirect.cpp:48-69) --------------------------------------------
+      e_new = st;
       if (LEARN) {
-        const uint32_t sn = seen_a ? ns : 0u;  // the uninitialised state learns as state 0
-        const float pa = nsp[sn];
-        const float na = pa + ((float)bit - gmx_logistic_tab(pa, s_tab)) * d.lr;
-        const float nb = qb + ((float)bit - gmx_logistic_tab(qb, s_tab)) * d.lr;
-        const uint32_t e_new = (uint32_t)nsn[2 * sn + bit] | ((uint32_t)rmn[2 * rm + bit] << 8);
-        nsp[sn] = na;
-        rmp[rm] = nb;
-        tab[idx[j]] = (uint16_t)e_new;
-        if (patch) {
+        uint32_t sn = st;
+        float p = q;
+        if (half == 0) {  // the uninitialised nonstationary state learns as state 0 (the run map at its state)
+          sn = seen ? st : 0u;
+          p = seen ? q : p0;
+        }
+        const float n = p + ((float)bit - gmx_logistic_tab(p, s_tab)) * d.lr;
+        e_new = nextp[2 * sn + bit];
+        lp[sn] = n;
+        tab[2ull * cur.idx[j]] = (uint8_t)e_new;
+        if (!cur.shaped) {
 #pragma unroll
           for (int i = j + 1; i < D; ++i)  // the same entry again later in this block
-            e[i] = idx[i] == idx[j] ? e_new : e[i];
+            cur.e[i] = cur.idx[i] == cur.idx[j] ? e_new : cur.e[i];
         }
       }
-    }
+    };
+
+    Recs rn, rf;      // records of the next block (landed) and of the one after it (in flight)
+    uint32_t bit_c[D];  // the bits of the current block
+    Block cur, nxt;
+    {
+      Recs r0;
+      load_records(r0, 0);
+      load_records(rn, D);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pin_records(r0);
+      pin_records(rn);
+      block_indices(cur, r0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pin_entries(cur);
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-      ctx_r[j] = ctx_n[j];
-      bc_r[j] = bc_n[j];
-      bit_r[j] = bit_n[j];
+      for (int j = 0; j < D; ++j) bit_c[j] = r0.bit[j];
     }
-  }
-  slots[2 * ml] = va;
-  slots[2 * ml + 1] = vb;
+    uint64_t t0 = 0;
+    for (; t0 + D <= T; t0 += D) {  // full blocks
+      IND_STAMP(4);
+      load_records(rf, t0 + 2 * D);
+      IND_STAMP(0);
+      block_indices(nxt, rn);
+      IND_STAMP(1);
+      uint32_t e_new[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) do_bit(cur, j, bit_c[j], e_new[j]);
+      IND_STAMP(2);
+      if (t0 + D < T) {
+        if (!LEARN || (cur.shaped && nxt.clean)) {
+          // the entries were asked for before this block's stores: they are there once at most those stores
+          // are outstanding
+          if (kStoresPerBlock > 0) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kStoresPerBlock) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          pin_entries(nxt);
+          if (LEARN) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) nxt.e[j] = nxt.idx[j] == cur.idx[j] ? e_new[j] : nxt.e[j];
+          }
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int j = 0; j < D; ++j) ind_ld8(nxt.e[j], tab + 2ull * nxt.idx[j]);  // behind the stores: current
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          pin_entries(nxt);
+        }
+        pin_records(rf);
+      }
+      IND_STAMP(3);
+      cur = nxt;
+#pragma unroll
+      for (int j = 0; j < D; ++j) bit_c[j] = rn.bit[j];
+      rn = rf;
+    }
+    if (t0 < T) {  // the last, partial block
+      uint32_t e_new;
+      cur.shaped = false;  // its records past T are clamped copies: entries repeat
+#pragma unroll
+      for (int j = 0; j < D; ++j)
+        if (t0 + j < T) do_bit(cur, j, bit_c[j], e_new);
+    }
+#ifdef GMX_IND_PROF
+    if (prof_on)
+      for (int i = 0; i < 8; ++i) atomicAdd(&gmx_ind_prof[i], prof_acc[i]);
+#endif
+  }  // if (on)
+  if (on) slots[2 * ml + half] = val;
   __syncthreads();
   if (LEARN)
-    for (int i = lane; i < K * 512; i += 64) gp[i] = ptab[i];
+    for (int i = threadIdx.x; i < K * 512; i += 128) gp[i] = ptab[i];
 }
+
+#ifdef GMX_IND_PROF
+extern "C" int gmx_indirect_prof_read(unsigned long long* out, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(gmx_ind_prof), sizeof(unsigned long long) * 8);
+  if (e == hipSuccess && reset) {
+    unsigned long long z[8] = {0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(gmx_ind_prof), z, sizeof z);
+  }
+  return (int)e;
+}
+#endif
 
 template <bool OUT, bool MX, bool LEARN>
 static hipError_t ind_launch_as(const GmxIndDev* dv, const GmxIndRunArgs* args, int n_streams, unsigned lds_bytes,
@@ -255,13 +394,14 @@ static hipError_t ind_launch_as(const GmxIndDev* dv, const GmxIndRunArgs* args, 
     if (e != hipSuccess) return e;
     allowed = lds_bytes;
   }
-  hipLaunchKernelGGL((gmx_indirect_kernel<OUT, MX, LEARN>), dim3(n_streams), dim3(64), lds_bytes, stream, dv, *args);
+  hipLaunchKernelGGL((gmx_indirect_kernel<OUT, MX, LEARN>), dim3(n_streams), dim3(128), lds_bytes, stream, dv, *args);
   return hipGetLastError();
 }
 
 extern "C" hipError_t gmx_launch_indirect_kernel(const GmxIndDev* dv, const GmxIndRunArgs* args, int n_streams,
                                                  unsigned lds_bytes, hipStream_t stream) {
   (void)hipGetLastError();
+  if (args->mx_pred && (args->mx_mask_words < 1 || args->mx_mask_words > 8)) return hipErrorInvalidValue;
   const bool out = args->pred_out != nullptr, mx = args->mx_pred != nullptr, learn = args->learn != 0;
   if (out) {
     if (mx) return learn ? ind_launch_as<true, true, true>(dv, args, n_streams, lds_bytes, stream)

@@ -221,3 +221,44 @@ def test_indirect_device_synth_is_the_oracles_stream(gpu, oracle):
         assert g.export(s) == ob.export()
     b.close()
     g.close()
+
+
+@pytest.mark.parametrize("shape", ["random", "shifted_bytes", "near_contexts", "repeated_bytes"])
+def test_indirect_block_pipeline_on_irregular_records(gpu, oracle, shape):
+    """The batched kernel fetches a block's table entries one block ahead and patches what the block in
+    between wrote.  Records that are not the reference's byte-shaped ones take its other paths: entries that
+    repeat inside a block and across blocks, bit_context >= 256, blocks that straddle bytes, contexts whose
+    index ranges overlap, a launch length that is no multiple of the block."""
+    _, z = goldenlib.load("ind_tiny_dense")
+    tabs = (z["ns_next"], z["rm_next"])
+    models = [(256, 0.02), (3, 0.1), (4096, 0.005), (1, 0.5), (65536, 0.02), (7, 0.05)]
+    K, T, S = len(models), 1237, 3
+    streams = []
+    for s in range(S):
+        rng = np.random.default_rng(77 + s)
+        bits = rng.integers(0, 2, T).astype(np.uint8)
+        if shape == "random":  # nothing byte-like: few contexts, any bit_context
+            ctx = rng.integers(0, 5, (T, K)).astype(np.uint32)
+            bc = rng.integers(0, 300, T).astype(np.uint32)
+        else:
+            nb = T // 8 + 2
+            byte_ctx = rng.integers(0, 3 if shape == "repeated_bytes" else 50, (nb, K)).astype(np.uint32)
+            if shape == "near_contexts":  # context c and c+1 of a 1-entry ... tables: (c << 8) % size wraps into its neighbours
+                byte_ctx = (rng.integers(0, 2, (nb, K)) + 0xffffff).astype(np.uint32)
+            byte_val = rng.integers(0, 2 if shape == "repeated_bytes" else 256, nb)
+            off = 3 if shape == "shifted_bytes" else 0  # blocks of 8 start 3 bits into a byte
+            ctx = np.zeros((T, K), np.uint32)
+            bc = np.zeros(T, np.uint32)
+            for t in range(T):
+                by, j = divmod(t + off, 8)
+                ctx[t] = byte_ctx[by]
+                bc[t] = (1 << j) | (int(byte_val[by]) >> (8 - j))
+                bits[t] = (int(byte_val[by]) >> (7 - j)) & 1
+        streams.append((ctx, bc, bits))
+    g, P, A = run_batched(gpu, models, tabs, streams, 1237)
+    for s in range(S):
+        ob = oracle.IndirectBank(models, *tabs)
+        p, a = ob.run(*streams[s])
+        assert np.array_equal(u32(P[s]), u32(p)) and np.array_equal(A[s], a), (shape, s)
+        assert g.export(s) == ob.export()
+    g.close()
