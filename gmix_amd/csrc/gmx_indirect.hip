@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "gmx_internal.h"
 #include "gmx_math.h"
 
@@ -165,12 +167,19 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
     };
     uint32_t prev_ctx = 0, base = 0;
     bool have_base = false;
+    // x % size without a division: q = mulhi(x, floor(2^32 / size)) is the quotient or one less
+    const uint32_t magic = d.size == 1u ? 0xffffffffu : (uint32_t)(0x100000000ull / d.size);
+    auto residue = [&](uint32_t x) -> uint32_t {
+      uint32_t r = x - __umulhi(x, magic) * d.size;
+      r = r < r - d.size ? r : r - d.size;  // min(r, r - size): r - size wraps when r < size
+      return r < r - d.size ? r : r - d.size;
+    };
     // ((context << 8) + bit_context) % size (indirect.cpp:31-32, 32-bit wrap), any records.  A model's
     // context changes once per byte, so the residue of (context << 8) is kept.
     auto index_of = [&](uint32_t ctx, uint32_t bcu) -> uint32_t {
       const bool moved = !have_base || ctx != prev_ctx;
       if (__ballot(moved)) {  // wave-uniform
-        const uint32_t nb = (ctx << 8) % d.size;
+        const uint32_t nb = residue(ctx << 8);
         base = moved ? nb : base;
         prev_ctx = ctx;
         have_base = true;
@@ -179,7 +188,7 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
         const uint32_t ix = base + bcu;
         return ix >= d.size ? ix - d.size : ix;
       }
-      return ((ctx << 8) + bcu) % d.size;
+      return residue((ctx << 8) + bcu);
     };
     auto load_records = [&](Recs& r, uint64_t t_first) {
       if (t_first + D <= T) {
@@ -218,7 +227,7 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
       if (blk.shaped) {
         const bool moved = !have_base || r.ctx[0] != prev_ctx;
         if (__ballot(moved)) {
-          const uint32_t nb = (r.ctx[0] << 8) % d.size;
+          const uint32_t nb = residue(r.ctx[0] << 8);
           base = moved ? nb : base;
         }
         prev_ctx = r.ctx[0];
@@ -253,7 +262,8 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
     const bool bit_writer = half == 0 && lane == 0;
 
     // one bit of block `cur`: Indirect::Predict, the outputs, Indirect::Learn; e_new = the entry afterwards
-    auto do_bit = [&](Block& cur, int j, uint32_t bit, uint32_t& e_new) {
+    auto do_bit = [&](Block& cur, int j, uint32_t bit, uint32_t& e_new, auto shaped_tag) {
+      constexpr bool kShaped = decltype(shaped_tag)::value;
       // ---- Indirect::Predict (indirect.cpp:28-46) ------------------------------------------
       const uint32_t st = cur.e[j];
       const float q = lp[st];
@@ -294,7 +304,7 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
         e_new = nextp[2 * sn + bit];
         lp[sn] = n;
         tab[2ull * cur.idx[j]] = (uint8_t)e_new;
-        if (!cur.shaped) {
+        if (!kShaped) {
 #pragma unroll
           for (int i = j + 1; i < D; ++i)  // the same entry again later in this block
             cur.e[i] = cur.idx[i] == cur.idx[j] ? e_new : cur.e[i];
@@ -326,8 +336,13 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
       block_indices(nxt, rn);
       IND_STAMP(1);
       uint32_t e_new[D];
+      if (cur.shaped) {  // one branch per block, not one per bit
 #pragma unroll
-      for (int j = 0; j < D; ++j) do_bit(cur, j, bit_c[j], e_new[j]);
+        for (int j = 0; j < D; ++j) do_bit(cur, j, bit_c[j], e_new[j], std::true_type{});
+      } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j) do_bit(cur, j, bit_c[j], e_new[j], std::false_type{});
+      }
       IND_STAMP(2);
       if (t0 + D < T) {
         if (!LEARN || (cur.shaped && nxt.clean)) {
@@ -360,7 +375,7 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
       cur.shaped = false;  // its records past T are clamped copies: entries repeat
 #pragma unroll
       for (int j = 0; j < D; ++j)
-        if (t0 + j < T) do_bit(cur, j, bit_c[j], e_new);
+        if (t0 + j < T) do_bit(cur, j, bit_c[j], e_new, std::false_type{});
     }
 #ifdef GMX_IND_PROF
     if (prof_on)
