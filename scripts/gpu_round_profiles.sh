@@ -8,11 +8,16 @@ bash scripts/gpu_profile.sh bench_single --config single --steps 12
 bash scripts/gpu_profile.sh synth3 --config synth3 --steps 6
 bash scripts/gpu_profile.sh stock_held --config stock_held --steps 8
 bash scripts/gpu_profile.sh stock_fresh --config stock_fresh --steps 8
+bash scripts/gpu_profile.sh stock_real --config stock_real --steps 8
 for c in "1024 --config stock_held --streams 1024" "256 --config stock_held --streams 256" "1 --config stock_S1"; do
   set -- $c; tag=$1; shift
   echo "== $* " >> gpurun_out/stock_waits.txt
   bash scripts/gpu_profile_waits.sh w$tag "$@" --steps 4 >> gpurun_out/stock_waits.txt 2>&1
 done
 export GMX_LIB=$PWD/gmix_amd/libgmxmix_prof.so
-for c in "1 4096 2" "256 256 2" "1024 256 2" "1024 256 0"; do timeout -k 10 120 python3 scripts/stock_phase_profile.py $c; done > gpurun_out/stock_phase_profile.txt 2>&1
+for c in "1 4096 2" "256 256 2" "1024 256 2" "1024 256 4" "1024 256 0"; do timeout -k 10 120 python3 scripts/stock_phase_profile.py $c; done > gpurun_out/stock_phase_profile.txt 2>&1
+unset GMX_LIB
+bash scripts/gpu_profile_indirect.sh
+timeout -k 10 300 python3 scripts/bench_indirect.py > gpurun_out/indirect_bench.json 2> gpurun_out/indirect_bench.err
+timeout -k 10 300 python3 scripts/bench_real_trace.py > gpurun_out/real_trace.json 2> gpurun_out/real_trace.err
 echo done

@@ -6,7 +6,11 @@ S="--no-cpu-baseline --no-also"
 python3 scripts/pmc_summary.py bench_single $R gmx_single_kernel 4096 512 3080 "python bench.py --config single --steps 12 $S" 0 > /dev/null
 python3 scripts/pmc_summary.py synth3 $R gmx_wide_kernel 1024 512 54608 "python bench.py --config synth3 --steps 6 $S" 0 > /dev/null
 python3 scripts/pmc_summary.py stock_held $R gmx_stock_kernel 1024 256 3193 "python bench.py --config stock_held --steps 8 $S" 2 > /dev/null
+python3 scripts/pmc_summary.py stock_real $R gmx_stock_kernel 1024 256 4943 "python bench.py --config stock_real --steps 8 $S" 4 > /dev/null
 python3 scripts/pmc_summary.py stock_fresh $R gmx_stock_kernel 1024 256 22072 "python bench.py --config stock_fresh --steps 8 $S" 0 > /dev/null
+python3 scripts/pmc_summary.py indirect $R gmx_indirect_kernel 256 4096 743 "python scripts/bench_indirect.py" 0 > /dev/null
+cp gpurun_out/indirect_bench.json profiles/r$(printf %02d $R)_indirect_bench.json
+cp gpurun_out/real_trace.json profiles/r$(printf %02d $R)_real_trace_bench.json
 cp gpurun_out/stock_phase_profile.txt profiles/r$(printf %02d $R)_stock_phase_profile.txt
 python3 - "$R" <<'PY'
 import csv, glob, collections, json, sys
@@ -26,6 +30,6 @@ open(f"profiles/r{R:02d}_stock_waits.txt", "w").write(
     + "\n".join(out) + "\n")
 for f in sorted(glob.glob(f"profiles/r{R:02d}_*_pmc_summary.json")):
     d = json.load(open(f))
-    print(f.split("/")[-1], d["kernel"].split("(")[0][-40:], "ms", round(d["kernel_ms_avg_rocprof"], 4), "traffic/alg", round(d["traffic_over_algorithmic"], 3), d["build"][-12:])
+    print(f.split("/")[-1], d["kernel"].split("(")[0][-40:], "ms", round(d["kernel_ms_avg_rocprof"], 4), "traffic/alg", round(d["traffic_over_algorithmic"], 3), (d.get("build") or "-")[-12:])
 print("\n".join(out))
 PY
