@@ -16,6 +16,8 @@ way (barrier, K steps, max over ranks) with its own roofline and one-core refere
   stock_real   the same with the row-change pattern of a real gmix run (the four bit-level contexts move every bit)
   stock_fresh  the same with every gate context new every bit (worst case)
   stock_S1     ONE stream of the reference's shape: what a single compressor sees
+  indirect     (one GPU) the 41 Indirect models in front of the mixers, 256 streams -- scripts/bench_indirect.py
+  lstm         (one GPU) the LSTM byte model, 1024 streams, bytes/s -- scripts/bench_lstm.py
 (--no-also leaves them out; --config X makes X the headline workload for profiling.)
 
 N > 1: one rank per GPU over RCCL.  Under torch.distributed.run the ranks come from the environment;
@@ -60,6 +62,16 @@ WORKLOADS = {
                  "ONE stream of the stock 24/8/1 topology (90 inputs), gate contexts redrawn every 8th bit, forward+update"),
 }
 ALSO = ("synth3", "stock_held", "stock_real", "stock_fresh", "stock_S1")
+
+
+def aux_bench(script):
+    """scripts/<script> as a module (its measure() returns one result object in this file's conventions)."""
+    import importlib.util
+    path = os.path.join(ROOT, "scripts", script)
+    spec = importlib.util.spec_from_file_location(script[:-3], path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def make_topology(kind):
@@ -361,6 +373,16 @@ def main():
         if rank == 0 and "cpu_baseline" in also.get("stock_held", {}) and "error" not in also.get("stock_S1", {"error": 1}):
             # one stream of the same workload: the one-core reference figure is the same measurement
             also["stock_S1"]["cpu_baseline"] = dict(also["stock_held"]["cpu_baseline"])
+        if world == 1:
+            # the producers in front of the mixers, timed by their own scripts' code:
+            # the 41 Indirect models (bits/s) and the LSTM byte model (bytes/s), each with roofline + cpu_baseline
+            for name, script, kw in (("indirect", "bench_indirect.py", {}), ("lstm", "bench_lstm.py", {})):
+                try:
+                    also[name] = aux_bench(script).measure(**kw)
+                    if args.no_cpu_baseline:
+                        also[name].pop("cpu_baseline", None)
+                except Exception as e:
+                    also[name] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         out = {"metric": "mixer bits/sec (synthetic 256-input mixer streams, forward+update)",
                "value": head["value"], "unit": "bits/s", "n_gpus": world, "steps": head["steps"],

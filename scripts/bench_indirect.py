@@ -26,12 +26,17 @@ def main():
     ap.add_argument("--into-mixer", action="store_true", help="also write into a stock mixer batch and run the mixers")
     ap.add_argument("--cpu-sample-bits", type=int, default=400_000)
     args = ap.parse_args()
+    print(json.dumps(measure(args.streams, args.bits, args.steps, args.warmup, args.cpu_sample_bits, args.into_mixer)))
+
+
+def measure(streams=256, bits=4096, steps=8, warmup=2, cpu_sample_bits=400_000, into_mixer=False):
+    """One result object in bench.py's conventions (also what bench.py's `also.indirect` carries)."""
     import gmix_amd
     import goldenlib
     from gmix_amd import topology
     _, z = goldenlib.load("ind_tiny_dense")  # carries the reference's two next-state tables
     models = topology.stock_indirect()
-    K, S, T = len(models), args.streams, args.bits
+    K, S, T = len(models), streams, bits
     mods = (300, 0, 70000, 5)
     slots = [(8 + 2 * i, 9 + 2 * i) for i in range(K)]
     g = gmix_amd.IndirectGroup(models, z["ns_next"], z["rm_next"], S, slots=slots)
@@ -39,13 +44,13 @@ def main():
     for i, b in enumerate(ring):
         b.fill_synthetic(T, seed=77 + i, restart=True, ctx_mod=mods)
     mg = mb = None
-    if args.into_mixer:
+    if into_mixer:
         mg = gmix_amd.MixerGroup(topology.stock(90), S)
         mb = gmix_amd.Batch(mg, T, outputs=False, mask=True)
         mb.fill_synthetic(T, seed=5, restart=True, ctx_mode=2)
         mg.sync()
     g.sync()
-    for k in range(args.warmup):
+    for k in range(warmup):
         g.run(ring[k % 2], T, learn=True, into=mb)
         if mg:
             mg.run(mb, T, learn=True)
@@ -54,7 +59,7 @@ def main():
         mg.sync()
     ms = []
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         ms.append(g.run(ring[k % 2], T, learn=True, into=mb, timed=True))
         if mg:
             mg.run(mb, T, learn=True)
@@ -66,8 +71,8 @@ def main():
     # algorithmic bytes per stream-bit: per model one 2-byte state pair read and written; the
     # record (contexts, bit_context, bit) read; two predictions + two flags per model written
     bpb = K * 4 + K * 4 + 5 + K * 10
-    out = {"metric": "indirect-model bits/sec (41 stock Indirect models, Predict+Learn)", "value": S * T * args.steps / el,
-           "unit": "bits/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+    out = {"metric": "indirect-model bits/sec (41 stock Indirect models, Predict+Learn)", "value": S * T * steps / el,
+           "unit": "bits/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
            "higher_is_better": True, "dtype": "u8/f32", "data": "synthetic",
            "config": {"workload": "41 stock Indirect models" + (" feeding the 33 stock mixers in HBM" if mg else ""),
                       "streams": S, "bits_per_stream_per_step": T, "bank_bytes_per_stream": g.bank_bytes},
@@ -76,7 +81,7 @@ def main():
                         "kernel_ms_avg": avg, "algorithmic_bytes_per_bit": bpb}}
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_indirect_harness")
     if os.path.exists(exe):
-        n = args.cpu_sample_bits
+        n = cpu_sample_bits
         t1 = time.perf_counter()
         subprocess.run([exe, "--models", ",".join(f"{t}:{lr!r}" for t, lr in models), "--bits", str(n),
                         "--ctx-mod", ",".join(map(str, mods)), "--out", "/tmp/_ind_cpu.bin"], check=True,
@@ -85,7 +90,14 @@ def main():
         out["cpu_baseline"] = {"value": n / dt, "unit": "bits/s", "cores": 1, "kind": "reference",
                                "sample": f"{n} bits through the reference's own Indirect class (strict -O2 harness, "
                                          f"incl. table construction and its checksum), 1 thread of {os.cpu_count()}"}
-    print(json.dumps(out))
+    for b in ring:
+        b.close()
+    if mb:
+        mb.close()
+    if mg:
+        mg.close()
+    g.close()
+    return out
 
 
 if __name__ == "__main__":

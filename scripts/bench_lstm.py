@@ -24,9 +24,14 @@ def main():
     ap.add_argument("--cpu-sample-bytes", type=int, default=20000)
     ap.add_argument("--no-learn", action="store_true", help="Predict only (generation mode)")
     args = ap.parse_args()
+    print(json.dumps(measure(args.streams, args.bytes, args.steps, args.warmup, args.cpu_sample_bytes, not args.no_learn)))
+
+
+def measure(streams=1024, nbytes=200, steps=4, warmup=1, cpu_sample_bytes=20000, learn=True):
+    """One result object in bench.py's conventions (also what bench.py's `also.lstm` carries)."""
     import gmix_amd
     from oracle import gmxo
-    S, N = args.streams, args.bytes
+    S, N = streams, nbytes
     g = gmix_amd.LstmGroup(S)
     w = gmxo.LstmModel().weights()
     for s in range(S):
@@ -38,13 +43,13 @@ def main():
         b.ppm[s] = ppm
         b.bytes[s] = np.roll(data, int(rng.integers(0, N)))
     b.upload(N)
-    for _ in range(args.warmup):
-        g.run(b, N, learn=not args.no_learn)
+    for _ in range(warmup):
+        g.run(b, N, learn=learn)
     g.sync()
     ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ms.append(g.run(b, N, learn=not args.no_learn, timed=True))
+    for _ in range(steps):
+        ms.append(g.run(b, N, learn=learn, timed=True))
     g.sync()
     el = time.perf_counter() - t0
     avg = sum(ms) / len(ms)
@@ -56,23 +61,25 @@ def main():
     bpb = (3 * 50 * 308 * 4 + 3 * 256 * 51 * 4 + 2 * 307 * 4 + 1024 + 256 * 51 * 4 + 3 * 50 * 50 * 4
            + (3 * 6 * 563 * 50 * 4 + 4 * 307 * 100 * 4) // 100)
     out = {"metric": "LSTM byte-model bytes/sec (Predict x 8 bits + Learn, backward pass every 100th byte)",
-           "value": S * N * args.steps / el, "unit": "bytes/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+           "value": S * N * steps / el, "unit": "bytes/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": el / steps * 1e3, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "LstmModel (Lstm(256,256,50,1,100,0.03,10))", "streams": S, "bytes_per_stream_per_step": N,
-                      "bank_bytes_per_stream": g.bank_bytes, "bits_per_s": S * N * 8 * args.steps / el},
+                      "bank_bytes_per_stream": g.bank_bytes, "bits_per_s": S * N * 8 * steps / el},
            "roofline": {"bound": "hbm", "achieved": bpb * S * N / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": bpb * S * N / (avg * 1e-3) / 1e9 / 8000.0, "traffic": None, "kernel": "gmx_lstm_kernel",
                         "kernel_ms_avg": avg, "algorithmic_bytes_per_byte": bpb}}
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_lstm_harness")
     if os.path.exists(exe):
-        n = args.cpu_sample_bytes
+        n = cpu_sample_bytes
         t1 = time.perf_counter()
         subprocess.run([exe, "--bytes", str(n), "--seed", "1", "--mask", "63", "--out", "/tmp/_lstm_cpu.bin"], check=True,
                        stdout=subprocess.DEVNULL)
         dt = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": n / dt, "unit": "bytes/s", "cores": 1, "kind": "reference",
                                "sample": f"{n} bytes through the reference's own LstmModel (strict -O2 harness), 1 thread of {os.cpu_count()}"}
-    print(json.dumps(out))
+    b.close()
+    g.close()
+    return out
 
 
 if __name__ == "__main__":
