@@ -1409,6 +1409,7 @@ extern "C" int gmx_debug_indirect_use_sessions(gmx_indirect* ib, int on) {
 extern "C" int gmx_lstm_set_cu_mask(gmx_lstm* l, const uint32_t* mask, int n_words) {
   if (!l || n_words < 0 || (n_words > 0 && !mask)) return GMX_ERR_INVALID;
   HIPCHK(hipSetDevice(l->device));
+  LSTM_CLOSE_SESSIONS(l);
   return stream_with_cu_mask(&l->stream, mask, n_words);
 }
 

@@ -243,6 +243,32 @@ struct GmxLstmRunArgs {
   uint32_t phases;         // 1: Lstm::Predict, 2: the 8 bit predictions, 4: Lstm::Perceive (when learn)
   int32_t stream_base;     // bank of block 0 (records of block 0 are always stream 0 of the arrays)
   int32_t last_byte;       // >= 0: ShortTermMemory::last_byte for the first Predict (else the bank remembers it)
+  // per-byte session (gmx_lstm_kernel<.., .., true>, one block): commands instead of records
+  struct GmxLstmMbCmd* mc;
+  struct GmxLstmMbReply* mb;
+  uint64_t idle_ticks;
+};
+
+// Mailbox of a per-byte session of the LSTM byte model: the protocol of the mixers' and the Indirect models'
+// sessions (command word = sequence << 4 | command, answered by the same word in done_seq).  Commands:
+// GMX_MB_FORWARD = Lstm::Predict on `ppm` with `last_byte`; GMX_MB_LEARN0 = Lstm::Perceive(`byte`) (with
+// `adam` when that byte's backward pass is due); GMX_MB_LEARN0_FWD = both, in that order.  One payload: the
+// model's state is in its bank whenever no wave runs, so nothing ever has to be replayed.
+struct GmxLstmMbCmd {      // host -> device: fine-grained device memory behind a large BAR, else pinned host memory
+  uint32_t cmd_seq;
+  uint32_t byte;           // the byte Lstm::Perceive learns
+  uint32_t last_byte;      // ShortTermMemory::last_byte at the Predict
+  uint32_t pad0;
+  float adam[4];           // alpha, 1 - beta1^t, 1 - beta2^t of the backward pass this Perceive runs (if it does)
+  uint32_t pad1[8];
+  float ppm[256];          // the PPM byte distribution (ShortTermMemory::ppm_predictions)
+};
+struct GmxLstmMbReply {    // device -> host: pinned host memory
+  uint32_t done_seq;
+  uint32_t state;          // GMX_MB_RUNNING / GMX_MB_EXIT_*
+  uint32_t context;        // lstm_prediction_context
+  uint32_t pad[13];
+  float probs[256];        // Lstm::Predict's distribution
 };
 
 #endif  // GMX_INTERNAL_H_

@@ -111,7 +111,11 @@ __device__ __forceinline__ float clipf(float a) { return a < -kClip ? -kClip : (
 
 }  // namespace
 
-template <int kStretch, int kBlocks>
+// SESSION: one persistent block that takes its work from a mailbox instead of record arrays (a decoder
+// knows a byte only after its eight predictions, coder/decoder.cpp:19-39): every command is one pass
+// through the loop below with the phases it names, the model's state stays in LDS and registers between
+// commands and goes back to the bank when the block leaves (GMX_MB_STOP, or idle_ticks without a command).
+template <int kStretch, int kBlocks, bool SESSION>
 __global__ void __launch_bounds__(256, kBlocks)
 gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
   __shared__ Lds L;
@@ -140,6 +144,15 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
   float prediction = __uint_as_float(scal[5]);
   if (a.last_byte >= 0) last_byte = (uint32_t)a.last_byte;
   uint32_t bptt_done = 0;
+  // what a pass through the loop does: fixed for a launch over records, named by each command of a session
+  uint32_t phases = a.phases;
+  bool learn = a.learn != 0;
+  const float* adam_row = adam_s;
+  volatile GmxLstmMbCmd* const vc = a.mc;
+  volatile GmxLstmMbReply* const vr = a.mb;
+  uint32_t seen = 0, word = 0, exit_state = GMX_MB_EXIT_IDLE;
+  bool fwd_after = false;  // the Predict half of a GMX_MB_LEARN0_FWD is still to run
+  if (SESSION) seen = __hip_atomic_load(&a.mb->done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __syncthreads();
 
 #ifdef GMX_LSTM_PROF
@@ -161,21 +174,76 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
     asm volatile("global_load_dword %0, %1, off" : "=v"(ppm_n) : "v"(p) : "memory");
   };
   auto ppm_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(ppm_n)); };
-  if (a.phases & 1u) {
+  if (!SESSION && (phases & 1u)) {
     ppm_request(0);
     ppm_landed();
   }
-  for (uint64_t n = 0; n < a.n_bytes; ++n) {
-    const uint32_t byte = bytes_s[n];
+  // a session's answer to the command just run (not yet after the Perceive half of a GMX_MB_LEARN0_FWD)
+  auto command_done = [&]() {
+    if (!SESSION || fwd_after) return;
+    if (phases & 1u) {
+      vr->probs[tid] = L.probs[tid];
+      if (tid == 0) vr->context = context;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    seen = word;
+    if (tid == 0) __hip_atomic_store(&a.mb->done_seq, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  for (uint64_t n = 0; SESSION || n < a.n_bytes; ++n) {
+    uint32_t byte = 0;
+    if (SESSION) {
+      if (fwd_after) {  // second half of GMX_MB_LEARN0_FWD
+        fwd_after = false;
+        phases = 1u;
+        learn = false;
+      } else {
+        if (tid == 0) {
+          const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+          uint32_t w = seen;
+          for (;;) {
+            w = __hip_atomic_load(&a.mc->cmd_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (w != seen) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > a.idle_ticks) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+          L.ired[2] = w;
+        }
+        __syncthreads();
+        word = L.ired[2];
+        __syncthreads();
+        if (word == seen) break;  // idle: leave (the state goes back to the bank below)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        const uint32_t cmd = word & GMX_MB_CMD_MASK;
+        if (cmd == GMX_MB_STOP) {
+          exit_state = GMX_MB_EXIT_STOP;
+          seen = word;
+          break;
+        }
+        fwd_after = cmd == GMX_MB_LEARN0_FWD;
+        phases = cmd == GMX_MB_FORWARD ? 1u : 4u;
+        learn = cmd != GMX_MB_FORWARD;
+      }
+      byte = vc->byte;
+      adam_row = (const float*)a.mc->adam;
+      bptt_done = 0;
+      if (phases & 1u) {
+        last_byte = vc->last_byte;
+        ppm_n = vc->ppm[tid];
+      }
+    } else {
+      byte = bytes_s[n];
+    }
     STAMP(0);
     bool sgd_done = false;
     // ======================= Lstm::Predict (lstm.cpp:95-123) ================================
-    if (a.phases & 1u) {
+    if (phases & 1u) {
       const uint32_t e = epoch, le = l_epoch;
       float* const lin = B + dv.layer_input + (uint64_t)e * LINP;
       // SetInput + the recurrent part of the layer input (lstm.cpp:45-50, :98-100)
       L.xin[tid] = ppm_n;
-      ppm_request(n + 1);
+      if (!SESSION) ppm_request(n + 1);
       if (tid < NC) L.xin[NI + tid] = L.hid[tid];
       if (tid == 0) L.xin[LIN - 1] = 1.0f;
       if (tid < NC) (B + dv.last_state + (uint64_t)le * CP)[tid] = cst;  // lstm-layer.cpp:200
@@ -290,7 +358,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       // starts from the matrix column this thread still holds, so do it now and read the ring
       // slot once instead of twice.  (Only when this launch also perceives, and knows the byte.)
       sgd_done = false;
-      if (a.learn && (a.phases & 4u) && epoch != 0) {
+      if (learn && (phases & 4u) && epoch != 0) {
         const float error = ((uint32_t)tid == byte) ? (p - 1.0f) : p;
         const float lr_e = kLearningRate * error;
         float* dst = out_layer + (uint64_t)epoch * HID * NO;
@@ -315,7 +383,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
     }
     STAMP(5);  // softmax sum, divide, context, early SGD
     // ======================= the 8 bit predictions (lstm-model.cpp:34-48) ====================
-    if ((a.phases & 2u) && tid < 8) {
+    if ((phases & 2u) && tid < 8) {
       const int k = tid;
       const int size = 256 >> k, half = size >> 1;
       const int bot = k == 0 ? 0 : (int)((byte >> (8 - k)) << (8 - k));
@@ -340,7 +408,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       L.nrm[1][k] = denom != 0.0f ? (p == 0.5f ? 1.0f : 2.0f) : 0.0f;  // 0 silent, 1 inactive, 2 active
     }
     __syncthreads();
-    if ((a.phases & 2u) && tid == 0) {
+    if ((phases & 2u) && tid == 0) {
       for (int k = 0; k < 8; ++k) {  // in bit order: a silent bit leaves the previous prediction
         const float st = L.nrm[1][k];
         if (st != 0.0f) prediction = L.nrm[0][k];
@@ -349,13 +417,14 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
       }
       ctx_s[n] = context;
     }
-    if (a.phases & 6u) {  // the byte is known from here on
+    if (phases & 6u) {  // the byte is known from here on
       last_byte = byte;
       coded = 1;
     }
-    if (!a.learn || !(a.phases & 4u)) {
-      if (a.phases & 1u) ppm_landed();
+    if (!learn || !(phases & 4u)) {
+      if (!SESSION && (phases & 1u)) ppm_landed();
       __syncthreads();
+      command_done();
       continue;
     }
     STAMP(6);  // bits
@@ -366,7 +435,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
     if (tid == 0) hist[last_epoch] = byte;
     __syncthreads();
     if (epoch == 0) {
-      const float alpha = adam_s[bptt_done * 4 + 0], d1 = adam_s[bptt_done * 4 + 1], d2 = adam_s[bptt_done * 4 + 2];
+      const float alpha = adam_row[bptt_done * 4 + 0], d1 = adam_row[bptt_done * 4 + 1], d2 = adam_row[bptt_done * 4 + 2];
       for (int ep = H - 1; ep >= 0; --ep) {
         STAMP(10);  // (previous epoch: neuron backward, clips)
         // output-layer error of this epoch and its pull on the hidden state (lstm.cpp:61-69)
@@ -641,8 +710,9 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
 #pragma unroll
       for (int j = 0; j < HID; ++j) dst[(uint64_t)j * NO + tid] = sv[j] - le * L.hid[j];
     }
-    if (a.phases & 1u) ppm_landed();
+    if (!SESSION && (phases & 1u)) ppm_landed();
     __syncthreads();
+    command_done();
   }
   // state back to the bank
   if (tid < CP) {
@@ -658,6 +728,16 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
     scal[4] = context;
     scal[5] = __float_as_uint(prediction);
     scal[6] = coded;
+  }
+  if (SESSION) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (tid == 0) {
+      if (exit_state == GMX_MB_EXIT_STOP)
+        __hip_atomic_store(&a.mb->done_seq, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&a.mb->state, exit_state, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -676,10 +756,17 @@ extern "C" hipError_t gmx_launch_lstm_kernel(const GmxLstmDev* dv, const GmxLstm
     if (e[0] == '3') build = 3;
   }
   if (build == 2)
-    hipLaunchKernelGGL((gmx_lstm_kernel<154, 2>), dim3(n_streams), dim3(256), 0, stream, dv, *args);
+    hipLaunchKernelGGL((gmx_lstm_kernel<154, 2, false>), dim3(n_streams), dim3(256), 0, stream, dv, *args);
   else
-    hipLaunchKernelGGL((gmx_lstm_kernel<GMX_LSTM_STRETCH, GMX_LSTM_BLOCKS>), dim3(n_streams), dim3(256), 0, stream,
+    hipLaunchKernelGGL((gmx_lstm_kernel<GMX_LSTM_STRETCH, GMX_LSTM_BLOCKS, false>), dim3(n_streams), dim3(256), 0, stream,
                        dv, *args);
+  return hipGetLastError();
+}
+
+// The per-byte session of ONE stream (args->stream_base; args->mc / mb / idle_ticks set).
+extern "C" hipError_t gmx_launch_lstm_session(const GmxLstmDev* dv, const GmxLstmRunArgs* args, hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL((gmx_lstm_kernel<154, 2, true>), dim3(1), dim3(256), 0, stream, dv, *args);
   return hipGetLastError();
 }
 

@@ -170,18 +170,31 @@ def test_lstm_checkpoint_import_export_copy(gpu, oracle):
     g2.close()
 
 
-def test_lstm_per_byte_surface_for_decoding(gpu, oracle):
+@pytest.mark.parametrize("sessions", [1, 0])
+def test_lstm_per_byte_surface_for_decoding(gpu, oracle, sessions):
     """gmx_lstm_forward / gmx_lstm_perceive: the byte distribution and lstm_prediction_context one
-    byte at a time, through a backward pass, then a batched launch continues the same stream."""
+    byte at a time, through two backward passes -- through the persistent per-byte session (commands in a
+    mailbox, the Perceive travelling with the next Predict) and with a kernel launch per call; the session
+    also across an idle exit and across calls that make it hand the bank back."""
+    import ctypes as C
+    import time
     N = 230
     ppm, data = oracle.lstm_synth(N, seed=21, mask=31)
     m = oracle.LstmModel()
     g = gpu.LstmGroup(2)
+    g.L.gmx_debug_lstm_use_sessions.argtypes = [C.c_void_p, C.c_int]
+    assert g.L.gmx_debug_lstm_use_sessions(g.h, sessions) == 0
     g.set_weights(m.weights(), stream=1)
     last = 0
     with pytest.raises(gpu.GmxError):
         g.perceive(3, stream=1)                    # Perceive before any Predict
-    for n in range(130):
+    for n in range(215):
+        if n == 60:
+            time.sleep(0.06)                       # longer than the session's idle timer: its block has left
+        if n == 95:
+            assert g.memory_usage() > 0 and len(g.export(0)[0]) > 0   # another stream's file: the session hands over
+        if n == 140:
+            g.sync()
         probs, ctx = g.forward(ppm[n], last, stream=1)
         p_ref, c_ref = m.predict_byte(ppm[n], last)
         assert np.array_equal(u32(probs), u32(p_ref)) and ctx == c_ref, n
