@@ -151,6 +151,7 @@ def lib():
     L.gmx_lockstep_batch.argtypes = [vp]
     L.gmx_lockstep_batch.restype = vp
     L.gmx_lockstep_predict.argtypes = [vp]
+    L.gmx_lockstep_is_persistent.argtypes = [vp]
     L.gmx_lockstep_learn.argtypes = [vp]
     L.gmx_lockstep_learn_predict.argtypes = [vp]
     for name in ("gmx_group_set_cu_mask", "gmx_indirect_set_cu_mask", "gmx_lstm_set_cu_mask"):
@@ -176,7 +177,7 @@ ABI_SYMBOLS = [
     "gmx_batch_bits", "gmx_batch_p", "gmx_batch_outputs", "gmx_batch_upload", "gmx_batch_download",
     "gmx_batch_wait", "gmx_batch_fill_synthetic", "gmx_group_run", "gmx_bank_export",
     "gmx_bank_import", "gmx_bank_copy", "gmx_bank_memory_usage",
-    "gmx_lockstep_create", "gmx_lockstep_destroy", "gmx_lockstep_batch", "gmx_lockstep_predict", "gmx_lockstep_learn", "gmx_lockstep_learn_predict",
+    "gmx_lockstep_create", "gmx_lockstep_destroy", "gmx_lockstep_batch", "gmx_lockstep_is_persistent", "gmx_lockstep_predict", "gmx_lockstep_learn", "gmx_lockstep_learn_predict",
     "gmx_indirect_create", "gmx_indirect_destroy", "gmx_indirect_n_streams", "gmx_indirect_n_models",
     "gmx_indirect_bank_bytes", "gmx_indirect_reset", "gmx_indirect_sync", "gmx_indirect_forward",
     "gmx_indirect_learn", "gmx_ind_batch_create", "gmx_ind_batch_destroy", "gmx_ind_batch_max_bits",

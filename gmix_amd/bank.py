@@ -259,14 +259,17 @@ def device_count():
 
 
 class Lockstep:
-    """All streams of a group one bit at a time, each half step one hipGraph (gmx_lockstep)."""
+    """All streams of a group one bit at a time (gmx_lockstep): each half step one hipGraph, or -- `persistent`,
+    where it applies -- S persistent waves behind one doorbell."""
 
-    def __init__(self, group, outputs=False):
+    def __init__(self, group, outputs=False, persistent=False):
         self.g = group
         self.L = group.L
         h = C.c_void_p()
-        check(self.L.gmx_lockstep_create(C.byref(h), group.h, BATCH_OUTPUTS if outputs else 0), "gmx_lockstep_create")
+        flags = (BATCH_OUTPUTS if outputs else 0) | (4 if persistent else 0)  # GMX_LOCKSTEP_PERSISTENT
+        check(self.L.gmx_lockstep_create(C.byref(h), group.h, flags), "gmx_lockstep_create")
         self.h = h
+        self.persistent = bool(self.L.gmx_lockstep_is_persistent(h))
         # the record batch is owned by the lock-step object: a Batch view that never destroys it
         b = Batch.__new__(Batch)
         b.g, b.L, b.max_bits = group, group.L, 1

@@ -243,10 +243,22 @@ struct gmx_lockstep {
   hipGraph_t g_predict = nullptr, g_learn = nullptr, g_step = nullptr;
   hipGraphExec_t x_predict = nullptr, x_learn = nullptr, x_step = nullptr;  // step = learn, then predict
   bool predicted = false;
+  // GMX_LOCKSTEP_PERSISTENT (gmx_stock_lockstep_kernel)
+  bool persistent = false, ps_running = false, ps_dead = false, ps_counted = false;
+  hipStream_t ps_stream = nullptr;
+  GmxLsDoor* door = nullptr;     // device memory the host writes through the BAR
+  uint32_t* done = nullptr;      // pinned host
+  uint32_t* blk_seen = nullptr;  // device [S]
+  uint32_t* blk_replay = nullptr;
+  uint32_t* relay = nullptr;     // device [64]: doorbell relay and arrival count (GmxLsArgs)
+  float* live = nullptr;         // device [S][GMX_LS_LIVE_FLOATS]
+  uint32_t seq = 0, word = 0, completed = 0;  // newest command published / known complete
+  bool learn_inflight = false;   // the newest command is a learn nobody has waited for
 };
 
-// per-bit sessions (gmx_session.inc)
+// per-bit sessions (gmx_session.inc); sessions_close also stops the persistent lock-step waves of the group
 static int sessions_close(gmx_group* g, bool keep_forward);
+static int locksteps_stop(gmx_group* g, gmx_lockstep* except);
 static void sessions_free(gmx_group* g);
 
 extern "C" const char* gmx_strerror(int status) {
@@ -1418,8 +1430,14 @@ extern "C" int gmx_lstm_set_cu_mask(gmx_lstm* l, const uint32_t* mask, int n_wor
 extern "C" int gmx_debug_lockstep_latency(gmx_group* g, int n, int ctx_hold, int fused, double* us_per_step) {
   if (!g || n <= 0 || ctx_hold <= 0 || !us_per_step) return GMX_ERR_INVALID;
   gmx_lockstep* ls = nullptr;
-  int rc = gmx_lockstep_create(&ls, g, 0);
+  const bool persistent = (fused & 2) != 0;  // bit 1: GMX_LOCKSTEP_PERSISTENT
+  fused &= 1;
+  int rc = gmx_lockstep_create(&ls, g, persistent ? GMX_LOCKSTEP_PERSISTENT : 0);
   if (rc) return rc;
+  if (persistent && !gmx_lockstep_is_persistent(ls)) {
+    gmx_lockstep_destroy(ls);
+    return GMX_ERR_STATE;
+  }
   gmx_batch* b = gmx_lockstep_batch(ls);
   const GmxTopoDev& t = g->topo;
   float* pred = gmx_batch_predictions(b);

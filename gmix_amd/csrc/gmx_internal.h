@@ -117,6 +117,39 @@ struct GmxMbReply {
   float outs[48];          // forward result: the 33 mixer outputs
 };
 
+// ---- lock step, persistent (gmx_stock_lockstep_kernel): S blocks, one doorbell ----------------------
+// The host writes the records of all S streams into pinned host arrays (the lock-step batch's own), then one
+// command word into `cmd_seq` (device memory behind the BAR, polled locally); block s reads ITS record
+// straight from the host arrays, answers into the host arrays and arrives at `arrived`; the last one to
+// arrive writes the word into *done (pinned host memory).  Commands: GMX_MB_FORWARD, GMX_MB_LEARN0 (= learn,
+// the coded bits are per stream, in `bits`), GMX_MB_LEARN0_FWD, GMX_MB_STOP.
+struct GmxLsDoor {          // device memory (fine-grained)
+  uint32_t cmd_seq;
+  uint32_t pad[15];
+};
+struct GmxLsArgs {
+  uint8_t* banks;
+  GmxLsDoor* door;
+  uint32_t* done;           // pinned host memory: newest command word completed by ALL blocks
+  const float* pred;        // pinned host [S][n_pad]
+  const uint32_t* mask;     // pinned host [S][mask_words]
+  const uint32_t* ctx;      // pinned host [S][m]
+  const uint8_t* bits;      // pinned host [S]: coded bits of the learn
+  const float* dec;         // pinned host [S]: decay factor of each stream's next learn, read at the forward
+  float* p;                 // pinned host [S]
+  float* outs;              // pinned host [S][m] or null
+  // per block, device memory: what survives a block that leaves on its idle timer
+  uint32_t* blk_seen;       // [S] last command word the block completed
+  uint32_t* blk_replay;     // [S] 1: it left between a forward and its learn (the forward is redone from `live`)
+  uint32_t* relay;          // device memory, L2-cached: [0] the doorbell's word as block 0 passes it on (a thousand
+                            // waves polling one uncached word would starve the host's own store to it), [32] the
+                            // count of blocks that have completed it
+  float* live;              // [S][GMX_LS_LIVE_FLOATS] the newest forward's record as the block read it
+  uint64_t idle_ticks;
+  int32_t n_streams, exact;
+};
+#define GMX_LS_LIVE_FLOATS 160  // pred[96] | mask[4] | ctx[36] | dec | pad
+
 // ---- Indirect models (models/indirect.cpp) -------------------
 #define GMX_IND_MAX_MODELS 64
 

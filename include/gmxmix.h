@@ -180,8 +180,16 @@ int gmx_bank_memory_usage(gmx_group* g, int stream, int mixer, uint64_t* bytes);
  * call gmx_lockstep_learn (asynchronous -- it works on a private copy of the bits, the array is the
  * caller's again when it returns; skip it for generation, runner-utils.cpp:199-209).
  * Same floats as every other surface.  Destroy before the group. */
+/* GMX_LOCKSTEP_PERSISTENT (the reference's own mixer shape, up to 128 streams -- beyond, a graph's bulk copies
+ * beat a thousand waves' small reads across the link): no graph launch and no stream synchronisation per step -- S persistent waves poll one doorbell,
+ * fetch their records straight from the host arrays and write the probabilities straight back (the arrays
+ * are read while gmx_lockstep_predict / _learn_predict run, never after they return).  Same calls, same
+ * floats; where it does not apply the flag is ignored and the graphs are used. */
+#define GMX_LOCKSTEP_PERSISTENT 4u
 typedef struct gmx_lockstep gmx_lockstep;
-int gmx_lockstep_create(gmx_lockstep** out, gmx_group* g, unsigned flags /* 0 or GMX_BATCH_OUTPUTS */);
+int gmx_lockstep_create(gmx_lockstep** out, gmx_group* g, unsigned flags /* GMX_BATCH_OUTPUTS | GMX_LOCKSTEP_PERSISTENT */);
+/* 1 if the object steps through persistent waves, 0 if through graphs */
+int gmx_lockstep_is_persistent(const gmx_lockstep* ls);
 void gmx_lockstep_destroy(gmx_lockstep* ls);
 gmx_batch* gmx_lockstep_batch(gmx_lockstep* ls);
 int gmx_lockstep_predict(gmx_lockstep* ls);

@@ -175,31 +175,40 @@ def test_per_bit_latency_report(gpu, capsys):
         where[sessions] = "device memory" if on_dev.value else "pinned host memory"
         g.close()
     steps = {}
-    for S in (1, 256, 1024):
+    for S in (1, 64, 256, 1024):
         g = gpu.MixerGroup(topo, S)
         g.L.gmx_debug_lockstep_latency.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         us = C.c_double()
-        for fused in (0, 1):
+        for fused in (0, 1, 2, 3):        # bit 0: learn + next predict as one step; bit 1: persistent waves
+            if (fused & 2) and S > 128:   # (the flag is ignored beyond 128 streams)
+                continue
             assert g.L.gmx_debug_lockstep_latency(g.h, 100, 8, fused, C.byref(us)) == 0
             assert g.L.gmx_debug_lockstep_latency(g.h, 1000, 8, fused, C.byref(us)) == 0
             steps[S, fused] = us.value
         g.close()
     with capsys.disabled():
         print(f"\n[lock-step Predict / host round trip / Learn, C ABI] one hipGraph per half step: "
-              + ", ".join(f"S = {S}: {steps[S, 0]:.1f}" for S in (1, 256, 1024)) + " us/step; learn + next predict as one graph: "
-              + ", ".join(f"S = {S}: {steps[S, 1]:.1f}" for S in (1, 256, 1024)) + " us/step")
+              + ", ".join(f"S = {S}: {steps[S, 0]:.1f}" for S in (1, 64, 256, 1024)) + " us/step; learn + next predict as one graph: "
+              + ", ".join(f"S = {S}: {steps[S, 1]:.1f}" for S in (1, 64, 256, 1024)) + " us/step; persistent waves behind one doorbell: "
+              + ", ".join(f"S = {S}: {steps[S, 2]:.1f}" for S in (1, 64)) + " us/step, learn + next predict as one command: "
+              + ", ".join(f"S = {S}: {steps[S, 3]:.1f}" for S in (1, 64)) + " us/step")
         print(f"[per-bit Predict+Learn, C ABI] session, commands in {where[1]}: {out[1, 1]:.1f} us/bit (new rows "
               f"every bit), {out[1, 8]:.1f} us/bit (contexts held 8 bits); in {where[2]}: {out[2, 1]:.1f} / "
               f"{out[2, 8]:.1f}; two launches: {out[0, 1]:.1f} / {out[0, 8]:.1f} us/bit")
     assert out[1, 8] < out[0, 8]
+    assert steps[64, 3] < steps[64, 1]
 
 
-@pytest.mark.parametrize("shape", ["stock", "general"])
+@pytest.mark.parametrize("shape", ["stock", "general", "stock_persistent"])
 def test_lockstep_graphs_equal_oracle(gpu, oracle, shape):
-    """gmx_lockstep: every stream one bit per step, each half step one hipGraph -- the floats and the
-    state of the batched surface and the oracle; a batched launch in between, generation (no Learn)
-    at the end, two streams that stand at different bit counts."""
-    topo = topology.stock(90) if shape == "stock" else topology.Topology(
+    """gmx_lockstep: every stream one bit per step, each half step one hipGraph -- or, GMX_LOCKSTEP_PERSISTENT,
+    persistent waves behind one doorbell that read the records from the host arrays themselves -- the floats
+    and the state of the batched surface and the oracle; a batched launch in between, generation (no Learn)
+    at the end, two streams that stand at different bit counts; the persistent waves also across idle exits
+    (before a Predict, and between a Predict and its Learn: the forward is redone from the wave's own copy)."""
+    import time
+    persistent = shape.startswith("stock_persistent")
+    topo = topology.stock(90) if shape != "general" else topology.Topology(
         40, [(0, 64, 0.004)] * 5 + [(1, 16, 0.003)] * 3 + [(2, 1, 0.0005)], skip=(1,))
     n, m = topo.n_inputs, topo.n_mixers
     S, T = 5, 420
@@ -215,18 +224,25 @@ def test_lockstep_graphs_equal_oracle(gpu, oracle, shape):
     ob3.run(*pre)
     g.import_(ob3.export_long(), ob3.export_short(), stream=3)
     refs[3] = (ob3,) + ob3.run(*recs[3], nolearn_from=400)
-    ls = gpu.Lockstep(g, outputs=True)
+    ls = gpu.Lockstep(g, outputs=True, persistent=persistent)
+    assert ls.persistent == persistent
     b = ls.batch
 
     def step(t, learn=True):
         for s in range(S):
             pred, act, ctx, bits = recs[s]
             b.set_records(s, pred[t:t + 1], act[t:t + 1], ctx[t:t + 1], np.zeros(1, np.uint8))
+        if persistent and t == 60:
+            time.sleep(0.06)                        # longer than the idle timer: the waves have left
         p = ls.predict()
         for s in range(S):
             assert np.array_equal(u32(b.outputs[s, 0]), u32(refs[s][2][t])), (t, s)
             assert np.float32(p[s]).view(np.uint32) == refs[s][1][t].view(np.uint32), (t, s)
             b.bits[s, 0] = recs[s][3][t]
+        if persistent and t == 100:
+            time.sleep(0.06)                        # ... between a Predict and its Learn
+            b.set_records(0, recs[0][0][:1], recs[0][1][:1], recs[0][2][:1], np.zeros(1, np.uint8))  # and its record is gone
+            b.bits[0, 0] = recs[0][3][t]
         if learn:
             ls.learn()
 
