@@ -169,3 +169,4 @@ def test_lstm_entry_points_reject_bad_arguments():
     assert L.gmx_lockstep_create(None, None, 0) == -1
     assert L.gmx_lockstep_predict(None) == -1 and L.gmx_lockstep_learn(None) == -1
     assert L.gmx_lockstep_learn_predict(None) == -1 and not L.gmx_lockstep_batch(None)
+    assert L.gmx_lockstep_is_persistent(None) == 0

@@ -46,6 +46,8 @@ def run(gpu, topo, streams, chunk, force_general, mask=True, learn=True, exact=F
     (dict(ctx_mode=0), True),                                  # every row changes every bit
     (dict(ctx_mode=3, ctx_mod=5, zero_mod=7, bit_mode=1), True),  # rows persist, silent models, learnable
     (dict(ctx_mode=1, ctx_mod=2, bit_mode=1), False),           # >1024 visits per row: shrink; no mask
+    (dict(ctx_mode=4, zero_mod=11, bit_mode=1), True),          # a real run's pattern: 4 rows move every bit (the sparse path)
+    (dict(ctx_mode=5, ctx_mod=3, bit_mode=1), False),           # ... between a handful of rows: write-back, refetch, shrink
 ])
 def test_stock_kernel_equals_general_kernel_and_oracle(gpu, oracle, kw, mask):
     topo = topology.stock(90)
@@ -134,8 +136,8 @@ def test_staged_rows_with_every_simd_busy(gpu, oracle):
         g.L.gmx_debug_stock_staged.argtypes = [C.c_void_p, C.c_int]
         assert g.L.gmx_debug_stock_staged(g.h, staged) == 0
         b = gpu.Batch(g, T, outputs=False, mask=False)
-        for rep in range(2):  # the second pass revisits rows the first one wrote back
-            b.fill_synthetic(T, seed=4242, restart=True, ctx_mode=2 if rep == 0 else 0, ctx_mod=1)
+        for rep in range(3):  # later passes revisit rows the first one wrote back; the third moves 4 rows per bit
+            b.fill_synthetic(T, seed=4242, restart=True, ctx_mode=(2, 0, 4)[rep], ctx_mod=1)
             g.run(b, T)
         b.download(T)
         b.wait()
@@ -149,6 +151,7 @@ def test_staged_rows_with_every_simd_busy(gpu, oracle):
         ob = oracle.Bank(90, topo.skip, topo.mixers)
         seed = (4242 + s * GOLD) % (1 << 64)
         ob.run(*oracle.synth(90, 33, T, seed=seed, ctx_mode=2, ctx_mod=1))
-        p_ref, _ = ob.run(*oracle.synth(90, 33, T, seed=seed, ctx_mode=0, ctx_mod=1))
+        ob.run(*oracle.synth(90, 33, T, seed=seed, ctx_mode=0, ctx_mod=1))
+        p_ref, _ = ob.run(*oracle.synth(90, 33, T, seed=seed, ctx_mode=4, ctx_mod=1))
         assert np.array_equal(outs[1][0][s].view(np.uint32), p_ref.view(np.uint32)), s
         assert outs[1][1][k] == (ob.export_long(), ob.export_short()), s
