@@ -354,6 +354,14 @@ static int build_topology(const gmx_topology* t, GmxTopoDev* o) {
   // anyway.  The spare quad is never moved as weights by any kernel of that shape.
   const bool fold = o->n == 90 && o->l0 == 24 && o->l1 == 8 && o->n_skip == 1 && o->has_final &&
                     o->mx[23].stride == 128;
+  // The 256-input 24/8/1 shape (gmx_wide.hip) keeps the counter inside the row too, right BEHIND the weights:
+  // the 16-byte piece after the last one that holds weights (float round_up(weight_size, 4) of a layer-0 row,
+  // float 36 of a layer-1 / final row) is padding no kernel of that shape moves -- gmx_wide.hip fetches and
+  // writes back only pieces with weights, the general kernel only quads below weight_size -- and it lies in the
+  // 64-byte sector the row's last weights travel in anyway, for 28 of the 33 rows (layer-0 rows 0 and 13..16 end
+  // on a sector boundary: those five still pay a sector each way).
+  const bool fold2 = o->n == 256 && o->l0 == 24 && o->l1 == 8 && o->n_skip == 1 && o->has_final &&
+                     o->mx[23].stride == 288;
   uint64_t off = 0;
   for (int j = 0; j < o->m; ++j) {
     o->mx[j].w_off = off;
@@ -361,10 +369,15 @@ static int build_topology(const gmx_topology* t, GmxTopoDev* o) {
   }
   for (int j = 0; j < o->m; ++j) {
     GmxMixerDev& x = o->mx[j];
-    x.rs_folded = fold ? 1u : 0u;
+    x.rs_folded = fold ? 1u : (fold2 ? 2u : 0u);
     if (fold) {
       if (x.stride < round_up(x.weight_size, 4) + 4u) return GMX_ERR_INVALID;
       x.rs_off = x.w_off + (uint64_t)x.stride * 4u - 8u;
+      x.rs_pitch = x.stride * 4u;
+    } else if (fold2) {
+      const uint32_t at = j < o->l0 ? round_up(x.weight_size, 4) : 36u;  // float index of the counter in the row
+      if (x.weight_size > at || at + 2u > x.stride) return GMX_ERR_INVALID;
+      x.rs_off = x.w_off + (uint64_t)at * 4u;
       x.rs_pitch = x.stride * 4u;
     } else {
       x.rs_off = off;

@@ -26,8 +26,9 @@ struct GmxMixerDev {
   uint64_t w_off;        // byte offset of the weight table inside a bank
   uint64_t rs_off;       // byte offset of row 0's step counter (MixerData::steps) ...
   uint32_t rs_pitch;     // ... and the byte distance to the next row's: 8 (a table of its own) or the row
-                         // length (folded: the counter is the last 8 bytes of the row's zero padding)
-  uint32_t rs_folded;
+                         // length (folded: the counter lives in the row's zero padding)
+  uint32_t rs_folded;    // 0: table of its own; 1: the last 8 bytes of the row (the reference's 90-input shape);
+                         // 2: right behind the weights (the 256-input 24/8/1 shape), see build_topology
 };
 
 // Address of the step counter of row `row` of mixer `mx` in the bank at `bank`.

@@ -428,7 +428,7 @@ gmx_bank_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
           // lanes past the stored row only skip the HBM store (exec mask inside the asm).
           const uint32_t c = 4u * (uint32_t)lr_;
           // (a folded step counter lives in the row's last quad: that quad is never stored as weights)
-          const uint64_t st_mask = __ballot(c < stride0 - (d.rs_folded ? 4u : 0u));
+          const uint64_t st_mask = __ballot(c < stride0 - (d.rs_folded == 1u ? 4u : 0u));
 #pragma unroll
           for (int m0 = 0; m0 < L0; m0 += RP) {
             const int m = m0 + sub;
@@ -517,7 +517,9 @@ gmx_bank_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
           w = w - u * x;
           w = sh ? w * shrink : w;
           lds[so + c] = w;
-          if (c < 60 || !d.rs_folded) gmx_vst4(g + (uint64_t)c * 4u, w);  // the last quad may hold the step counter
+          // (a folded step counter -- the last quad, or floats 36/37 behind the weights -- is never stored as weights)
+          const bool is_rs = d.rs_folded == 1u ? c >= 60 : (d.rs_folded == 2u && (c == 36 || c == 37));
+          if (!is_rs) gmx_vst4(g + (uint64_t)c * 4u, w);
         }
       }
     }

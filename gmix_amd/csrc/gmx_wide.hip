@@ -158,10 +158,11 @@ gmx_wide_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
     max_steps = scal[1];
     seen_cnt = scal[2];
   }
-  // Row r's step counter (gmx_internal.h): the 256-input banks keep a table of counters (8 bytes apart), the
-  // reference's own shape keeps each counter in the last 8 bytes of its row -- known at compile time here,
-  // which matters: this kernel sits at 256 VGPRs and a run-time pitch cost it 20 %.
-  constexpr bool kFolded = N == 90;
+  // Row r's step counter (gmx_internal.h): both shapes this kernel serves keep it inside the row's padding (the
+  // reference's own in the row's last 8 bytes, the 256-input banks right behind the weights; d.rs_off says
+  // where), one row length apart -- known at compile time here, which matters: this kernel sits at 256
+  // VGPRs and a run-time pitch cost it 20 %.
+  constexpr bool kFolded = true;
   uint64_t* const rs_tab = (uint64_t*)(bank + d.rs_off);
   uint8_t* const w_tab = bank + d.w_off + ((is_l0 && half) ? kHalf * 4u : 0u);
   const uint32_t row_bytes = d.stride * 4u;
