@@ -46,7 +46,7 @@ WORKLOADS = {
     #        one-core sample bits, description)
     "single": ("single", 0, 4096, 512, 100_000_000, 20_000_000,
                "configs[1]: synthetic 256-input 1-layer mixer (1 mixer, 2^16-row gate table), random logits, forward+update"),
-    "synth3": ("synth3", 0, 1024, 512, 8_000_000, 300_000,
+    "synth3": ("synth3", 0, 2048, 512, 8_000_000, 300_000,
                "synthetic 256-input 3-layer 24/8/1 bank (2^12-row layer-0 tables), new gate rows every bit, forward+update"),
     "stock": ("stock", 0, 1024, 256, 4_000_000, 400_000,
               "stock 24/8/1 topology of Predictor::AddMixers, 90 inputs, synthetic records, forward+update"),

@@ -4,7 +4,7 @@ R=${1:-2}
 cd "$(dirname "$0")/.."
 S="--no-cpu-baseline --no-also"
 python3 scripts/pmc_summary.py bench_single $R gmx_single_kernel 4096 512 3080 "python bench.py --config single --steps 12 $S" 0 > /dev/null
-python3 scripts/pmc_summary.py synth3 $R gmx_wide_kernel 1024 512 54608 "python bench.py --config synth3 --steps 6 $S" 0 > /dev/null
+python3 scripts/pmc_summary.py synth3 $R gmx_wide_kernel 2048 512 54608 "python bench.py --config synth3 --steps 6 $S" 0 > /dev/null
 python3 scripts/pmc_summary.py stock_held $R gmx_stock_kernel 1024 256 3193 "python bench.py --config stock_held --steps 8 $S" 2 > /dev/null
 python3 scripts/pmc_summary.py stock_real $R gmx_stock_kernel 1024 256 4943 "python bench.py --config stock_real --steps 8 $S" 4 > /dev/null
 python3 scripts/pmc_summary.py stock_fresh $R gmx_stock_kernel 1024 256 22072 "python bench.py --config stock_fresh --steps 8 $S" 0 > /dev/null

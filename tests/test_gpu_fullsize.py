@@ -1,5 +1,5 @@
 """BASELINE.json configs[1] at the bench's full size (4096 streams x 512 bits, 258 GiB of gate
-tables) and the 256-input 24/8/1 bank at ITS bench size (1024 streams x 512 bits) through properties that do not need the oracle to run 1.5 M bits: a launch split in two
+tables) and the 256-input 24/8/1 bank at bench scale (1024 streams x 512 bits: one wave on every SIMD; bench.py runs two) through properties that do not need the oracle to run 1.5 M bits: a launch split in two
 gives the same floats and the same banks; sampled streams equal the oracle run on the same seed;
 streams do not leak into each other."""
 import numpy as np
