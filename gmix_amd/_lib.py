@@ -97,6 +97,7 @@ def lib():
     L.gmx_indirect_bank_bytes.argtypes = [vp]
     L.gmx_indirect_bank_bytes.restype = u64
     L.gmx_indirect_forward.argtypes = [vp, i32, vp, u32, vp, vp]
+    L.gmx_chain_forward.argtypes = [vp, vp, i32, vp, u32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.gmx_indirect_learn.argtypes = [vp, i32, i32]
     L.gmx_ind_batch_create.argtypes = [C.POINTER(vp), vp, u64]
     L.gmx_ind_batch_destroy.argtypes = [vp]
@@ -179,7 +180,7 @@ ABI_SYMBOLS = [
     "gmx_bank_import", "gmx_bank_copy", "gmx_bank_memory_usage",
     "gmx_lockstep_create", "gmx_lockstep_destroy", "gmx_lockstep_batch", "gmx_lockstep_is_persistent", "gmx_lockstep_predict", "gmx_lockstep_learn", "gmx_lockstep_learn_predict",
     "gmx_indirect_create", "gmx_indirect_destroy", "gmx_indirect_n_streams", "gmx_indirect_n_models",
-    "gmx_indirect_bank_bytes", "gmx_indirect_reset", "gmx_indirect_sync", "gmx_indirect_forward",
+    "gmx_indirect_bank_bytes", "gmx_indirect_reset", "gmx_indirect_sync", "gmx_indirect_forward", "gmx_chain_forward",
     "gmx_indirect_learn", "gmx_ind_batch_create", "gmx_ind_batch_destroy", "gmx_ind_batch_max_bits",
     "gmx_ind_batch_contexts", "gmx_ind_batch_bit_contexts", "gmx_ind_batch_bits",
     "gmx_ind_batch_predictions", "gmx_ind_batch_active", "gmx_ind_batch_upload", "gmx_ind_batch_download",

@@ -1431,6 +1431,97 @@ extern "C" int gmx_debug_indirect_use_sessions(gmx_indirect* ib, int on) {
   ib->use_sessions = on != 0;
   return GMX_OK;
 }
+// ---- Indirect models -> mixers, one host round trip -------------------------------------------------
+// gmx_indirect_forward followed by gmx_bank_forward with the Indirect models' predictions and active flags put
+// into the mixers' inputs at the models' slots -- but when both banks answer through per-bit sessions on the
+// same device, the wave of the Indirect models hands its results to the mixers' wave itself and rings its
+// mailbox (GmxIndMbCmd::chain_*): the host waits once.  `predictions` / `active_models` are the blackboard as
+// it stands BEFORE the Indirect models' Predict (their slots are overwritten, their indices ignored if listed).
+// The Learn calls are the usual ones (gmx_indirect_learn, gmx_bank_learn): they are only noted and travel
+// with the next forward anyway.  Same floats as the two calls.
+extern "C" int gmx_chain_forward(gmx_indirect* ib, gmx_group* g, int stream, const uint32_t* ind_contexts,
+                                 uint32_t bit_context, const float* predictions, const int32_t* active_models,
+                                 int n_active, const uint32_t* contexts, float* p_final, float* out_all,
+                                 float* ind_predictions, uint8_t* ind_active) {
+  if (!ib || !g || stream < 0 || stream >= ib->S || stream >= g->S || !ind_contexts || !predictions || !contexts)
+    return GMX_ERR_INVALID;
+  if (n_active > 0 && !active_models) return GMX_ERR_INVALID;
+  const GmxTopoDev& t = g->topo;
+  const int K = ib->dev.k;
+  uint32_t own[4] = {0, 0, 0, 0};  // the active-mask bits of the Indirect models' slots
+  for (int i = 0; i < K; ++i) {
+    const int a = ib->dev.m[i].slot_a, b = ib->dev.m[i].slot_b;
+    if (a < 0 || a >= t.n || b < 0 || b >= t.n) return GMX_ERR_INVALID;
+    own[a >> 5] |= 1u << (a & 31);
+    own[b >> 5] |= 1u << (b & 31);
+  }
+  HIPCHK(hipSetDevice(g->device));
+  std::vector<float> ip((size_t)2 * K);
+  std::vector<uint8_t> ia((size_t)2 * K);
+  if (ib->device == g->device && ib->use_sessions && g->use_sessions && group_is_stock(g) && n_active >= 0) {
+    // the mixers' command first (payload in its slot, word decided, doorbell NOT rung) ...
+    int rc = session_forward_prepare(g, stream, predictions, active_models, n_active, contexts, own);
+    if (rc == GMX_OK) {
+      GmxSession* se = g->sessions[stream];
+      // ... then the Indirect models' forward, which rings it
+      rc = ind_session_forward(ib, stream, ind_contexts, bit_context, ip.data(), ia.data(), se->word, se->slot, se->mc);
+      if (rc == GMX_OK) {
+        ib->fwd_done[stream] = 2;
+        rc = session_forward_finish(g, stream, p_final, out_all);
+        if (rc == GMX_OK) g->fwd_done[stream] = 2;
+      } else {
+        // the Indirect side did not take the command: ring the mixers ourselves once its inputs are whole
+        int rc2 = rc == GMX_ERR_STATE ? gmx_indirect_forward(ib, stream, ind_contexts, bit_context, ip.data(), ia.data()) : rc;
+        if (rc2 == GMX_OK) {
+          GmxMbPayload* pay = &se->mc->slot[se->slot];
+          for (int i = 0; i < K; ++i) {
+            const int sl[2] = {ib->dev.m[i].slot_a, ib->dev.m[i].slot_b};
+            for (int h = 0; h < 2; ++h) {
+              pay->pred[sl[h]] = ip[2 * i + h];
+              if (ia[2 * i + h]) pay->mask[sl[h] >> 5] = pay->mask[sl[h] >> 5] | (1u << (sl[h] & 31));
+            }
+          }
+          session_ring(se);
+          rc2 = session_forward_finish(g, stream, p_final, out_all);
+          if (rc2 == GMX_OK) g->fwd_done[stream] = 2;
+        }
+        rc = rc2;
+      }
+      if (rc == GMX_OK) {
+        if (ind_predictions) memcpy(ind_predictions, ip.data(), ip.size() * 4);
+        if (ind_active) memcpy(ind_active, ia.data(), ia.size());
+      }
+      return rc;
+    }
+    if (rc != GMX_ERR_STATE) return rc;  // GMX_ERR_STATE: no session slot for the mixers, the two calls instead
+  }
+  // the two calls, the host in between
+  int rc = gmx_indirect_forward(ib, stream, ind_contexts, bit_context, ip.data(), ia.data());
+  if (rc) return rc;
+  std::vector<float> pr(predictions, predictions + t.n);
+  std::vector<int32_t> act;
+  for (int i = 0; i < n_active; ++i) {
+    const int idx = active_models[i];
+    if (idx < 0 || idx >= t.n) return GMX_ERR_INVALID;
+    if (!((own[idx >> 5] >> (idx & 31)) & 1u)) act.push_back(idx);
+  }
+  if (n_active < 0)
+    for (int idx = 0; idx < t.n; ++idx)
+      if (!((own[idx >> 5] >> (idx & 31)) & 1u)) act.push_back(idx);
+  for (int i = 0; i < K; ++i) {
+    const int sl[2] = {ib->dev.m[i].slot_a, ib->dev.m[i].slot_b};
+    for (int h = 0; h < 2; ++h) {
+      pr[sl[h]] = ip[2 * i + h];
+      if (ia[2 * i + h]) act.push_back(sl[h]);
+    }
+  }
+  rc = gmx_bank_forward(g, stream, pr.data(), act.data(), (int)act.size(), contexts, p_final, out_all);
+  if (rc) return rc;
+  if (ind_predictions) memcpy(ind_predictions, ip.data(), ip.size() * 4);
+  if (ind_active) memcpy(ind_active, ia.data(), ia.size());
+  return GMX_OK;
+}
+
 extern "C" int gmx_lstm_set_cu_mask(gmx_lstm* l, const uint32_t* mask, int n_words) {
   if (!l || n_words < 0 || (n_words > 0 && !mask)) return GMX_ERR_INVALID;
   HIPCHK(hipSetDevice(l->device));

@@ -536,6 +536,24 @@ gmx_indirect_session_kernel(const GmxIndDev* __restrict__ dv, uint8_t* banks, in
           vr->active_a = act_a;
           vr->active_b = act_b;
         }
+        const uint32_t chain_word = vc->chain_word;
+        if (chain_word) {
+          // ---- hand the predictions to the mixers' session and ring it (see GmxIndMbCmd) -----------
+          GmxMbCmd* const mmc = (GmxMbCmd*)vc->chain_mc;
+          volatile GmxMbPayload* const mp = &mmc->slot[vc->chain_slot & 1u];
+          uint32_t* const mwl = (uint32_t*)(rmn + 512);  // four mask words, composed in LDS (one wave: in order)
+          if (lane < 4) mwl[lane] = 0;
+          if (on) {
+            mp->pred[d.slot_a] = va;
+            mp->pred[d.slot_b] = vb;
+            if ((act_a >> lane) & 1ull) atomicOr(&mwl[d.slot_a >> 5], 1u << (d.slot_a & 31));
+            if ((act_b >> lane) & 1ull) atomicOr(&mwl[d.slot_b >> 5], 1u << (d.slot_b & 31));
+          }
+          if (lane < 4) mp->mask[lane] = mp->mask[lane] | mwl[lane];  // the host left these bits clear
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+          if (lane == 0) __hip_atomic_store(&mmc->cmd_seq, chain_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
     }
     if (replay) {

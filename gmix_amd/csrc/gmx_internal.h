@@ -178,7 +178,15 @@ struct GmxIndDev {
 // in done_seq).
 struct GmxIndMbCmd {       // host -> device: fine-grained device memory behind a large BAR, else pinned host memory
   uint32_t cmd_seq;        // sequence << 4 | payload slot << 3 | command
-  uint32_t pad0[13];
+  // A chained forward (gmx_chain_forward): after its Predict the wave puts the 2k predictions into the `pred`
+  // of payload slot `chain_slot` of the MIXERS' mailbox at `chain_mc` (at the models' slot indices), ORs the
+  // active bits into its `mask`, and rings that mailbox with `chain_word` -- the mixers start without the
+  // host having seen the predictions.  chain_word == 0: no chaining.
+  uint32_t chain_word;
+  uint32_t chain_slot;
+  uint32_t pad0;
+  uint64_t chain_mc;
+  uint32_t pad1[8];
   uint32_t bit_context[2]; // ShortTermMemory::bit_context, per payload slot
   // the models' aliased context variables, read at the Predict call.  Two slots, used alternately: the one
   // of the forward whose learn is still to come stays intact while the next is written, so a wave

@@ -56,6 +56,36 @@ namespace gmx {
 
 class GpuMixer;
 
+// The Indirect models' bank of a Predictor, as the mixers' bank of the same Predictor sees it.  The last
+// feature model in front of the mixers is an Indirect model (predictor.cpp:24-28), so its bank does not run at
+// its own Predict but hands contexts to the first mixer's: gmx_chain_forward then takes both banks through
+// ONE host round trip (the Indirect wave rings the mixers' wave itself).  GMX_CHAIN_FUSED=0 switches back to
+// one call per bank.
+struct ChainProducer {
+  virtual ~ChainProducer() {}
+  virtual bool Pending() const = 0;
+  virtual gmx_indirect* Handle() = 0;
+  virtual const uint32_t* Contexts() const = 0;
+  virtual uint32_t BitContext() const = 0;
+  // the results go where 41 x Indirect::Predict would have left them; nothing is pending afterwards
+  virtual void Deliver(ShortTermMemory& stm, const float* pred, const uint8_t* active) = 0;
+};
+inline std::map<const LongTermMemory*, ChainProducer*>& ChainProducers() {
+  static std::map<const LongTermMemory*, ChainProducer*> r;
+  return r;
+}
+inline std::map<const LongTermMemory*, int>& ChainConsumers() {  // Predictors whose mixers are on the device
+  static std::map<const LongTermMemory*, int> r;
+  return r;
+}
+inline bool ChainFused() {
+  static const bool on = [] {
+    const char* e = getenv("GMX_CHAIN_FUSED");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 // All mixers of one Predictor: one gmx_group with one stream.
 class GpuMixerBank {
  public:
@@ -72,6 +102,7 @@ class GpuMixerBank {
   ~GpuMixerBank() {
     if (group_) gmx_group_destroy(group_);
     Registry().erase(&ltm_);
+    ChainConsumers().erase(&ltm_);
   }
   GpuMixerBank(const GpuMixerBank&) = delete;
   GpuMixerBank& operator=(const GpuMixerBank&) = delete;
@@ -80,7 +111,7 @@ class GpuMixerBank {
 
  private:
   friend class GpuMixer;
-  GpuMixerBank(ShortTermMemory& stm, LongTermMemory& ltm) : stm_(stm), ltm_(ltm) {}
+  GpuMixerBank(ShortTermMemory& stm, LongTermMemory& ltm) : stm_(stm), ltm_(ltm) { ChainConsumers()[&ltm] = 1; }
   static std::map<const LongTermMemory*, std::weak_ptr<GpuMixerBank>>& Registry() {
     static std::map<const LongTermMemory*, std::weak_ptr<GpuMixerBank>> r;
     return r;
@@ -194,6 +225,7 @@ class GpuMixerBank {
       for (auto& row : ltm_.mixers[memory_index_[j]].mixer_table) row.reset();
   }
   void PredictAll(ShortTermMemory& stm);
+  void ToBlackboard(ShortTermMemory& stm);
   void LearnAll(const ShortTermMemory& stm) {
     Settle();
     Check("gmx_bank_learn", gmx_bank_learn(group_, 0, stm.new_bit));
@@ -213,6 +245,8 @@ class GpuMixerBank {
   std::vector<int> memory_index_;
   std::vector<float> outputs_;
   std::vector<uint32_t> contexts_;
+  std::vector<float> chain_pred_;
+  std::vector<uint8_t> chain_act_;
   std::vector<char> short_cache_, short_in_;
   bool import_pending_ = false, staged_ = false;
 };
@@ -274,9 +308,25 @@ inline void GpuMixerBank::PredictAll(ShortTermMemory& stm) {
   for (size_t j = 0; j < mixers_.size(); ++j) contexts_[j] = mixers_[j]->context();  // read at call time
   static_assert(sizeof(int) == sizeof(int32_t), "active_models is passed as it stands");
   float p = 0.5f;
-  Check("gmx_bank_forward",
-        gmx_bank_forward(group_, 0, &stm.predictions[0], stm.active_models.data(), (int)stm.active_models.size(),
-                         contexts_.data(), &p, outputs_.data()));
+  ChainProducer* ind = nullptr;
+  {
+    auto it = ChainProducers().find(&ltm_);
+    if (it != ChainProducers().end() && it->second->Pending()) ind = it->second;
+  }
+  if (ind) {
+    // the Indirect models' Predict of this bit is still to run: both banks in one round trip
+    chain_pred_.resize(128);  // two slots for each of at most 64 models (gmx_indirect_create's limit)
+    chain_act_.resize(128);
+    Check("gmx_chain_forward",
+          gmx_chain_forward(ind->Handle(), group_, 0, ind->Contexts(), ind->BitContext(), &stm.predictions[0],
+                            stm.active_models.data(), (int)stm.active_models.size(), contexts_.data(), &p,
+                            outputs_.data(), chain_pred_.data(), chain_act_.data()));
+    ind->Deliver(stm, chain_pred_.data(), chain_act_.data());
+  } else {
+    Check("gmx_bank_forward",
+          gmx_bank_forward(group_, 0, &stm.predictions[0], stm.active_models.data(), (int)stm.active_models.size(),
+                           contexts_.data(), &p, outputs_.data()));
+  }
   // mixer.cpp:99-105: where each Mixer::Predict leaves its result
   size_t j = 0;
   for (int k = 0; k < stm.num_layer0_mixers; ++k) stm.mixer_layer0_outputs[k] = outputs_[j++];
@@ -297,7 +347,7 @@ inline void GpuMixerBank::PredictAll(ShortTermMemory& stm) {
 class GpuIndirect;
 
 // All Indirect models of one Predictor: one gmx_indirect with one stream.
-class GpuIndirectBank {
+class GpuIndirectBank : public ChainProducer {
  public:
   static std::shared_ptr<GpuIndirectBank> For(ShortTermMemory& stm, LongTermMemory& ltm) {
     auto& reg = Registry();
@@ -311,13 +361,25 @@ class GpuIndirectBank {
   ~GpuIndirectBank() {
     if (h_) gmx_indirect_destroy(h_);
     Registry().erase(&ltm_);
+    ChainProducers().erase(&ltm_);
+  }
+  // ChainProducer
+  bool Pending() const override { return pending_; }
+  gmx_indirect* Handle() override { return h_; }
+  const uint32_t* Contexts() const override { return contexts_.data(); }
+  uint32_t BitContext() const override { return pending_bit_context_; }
+  void Deliver(ShortTermMemory& stm, const float* pred, const uint8_t* active) override {
+    pending_ = false;
+    std::copy(pred, pred + pred_.size(), pred_.begin());
+    std::copy(active, active + active_.size(), active_.begin());
+    ToBlackboard(stm);
   }
   GpuIndirectBank(const GpuIndirectBank&) = delete;
   GpuIndirectBank& operator=(const GpuIndirectBank&) = delete;
 
  private:
   friend class GpuIndirect;
-  GpuIndirectBank(ShortTermMemory& stm, LongTermMemory& ltm) : stm_(stm), ltm_(ltm) {}
+  GpuIndirectBank(ShortTermMemory& stm, LongTermMemory& ltm) : stm_(stm), ltm_(ltm) { ChainProducers()[&ltm] = this; }
   static std::map<const LongTermMemory*, std::weak_ptr<GpuIndirectBank>>& Registry() {
     static std::map<const LongTermMemory*, std::weak_ptr<GpuIndirectBank>> r;
     return r;
@@ -424,6 +486,7 @@ class GpuIndirectBank {
     }
   }
   void PredictAll(ShortTermMemory& stm);
+  void ToBlackboard(ShortTermMemory& stm);
   void LearnAll(const ShortTermMemory& stm) {
     Settle();
     Check("gmx_indirect_learn", gmx_indirect_learn(h_, 0, stm.new_bit));
@@ -445,6 +508,8 @@ class GpuIndirectBank {
   std::vector<float> pred_;
   std::vector<uint8_t> active_;
   bool import_pending_ = false;
+  bool pending_ = false;  // this bit's Predict waits for the mixers' (gmx_chain_forward)
+  uint32_t pending_bit_context_ = 0;
 };
 
 class GpuIndirect : public Model {
@@ -502,8 +567,19 @@ class GpuIndirect : public Model {
 inline void GpuIndirectBank::PredictAll(ShortTermMemory& stm) {
   Settle();
   for (size_t i = 0; i < models_.size(); ++i) contexts_[i] = models_[i]->context();
+  if (ChainFused() && ChainConsumers().count(&ltm_)) {
+    // this Predictor's mixers are on the device too and theirs is the next Predict (predictor.cpp:24-28):
+    // they take this bank along (ChainProducer)
+    pending_ = true;
+    pending_bit_context_ = stm.bit_context;
+    return;
+  }
   Check("gmx_indirect_forward",
         gmx_indirect_forward(h_, 0, contexts_.data(), stm.bit_context, pred_.data(), active_.data()));
+  ToBlackboard(stm);
+}
+
+inline void GpuIndirectBank::ToBlackboard(ShortTermMemory& stm) {
   // What 41 x Indirect::Predict leave on the blackboard (indirect.cpp:35-44 through SetLogitPrediction,
   // short-term-memory.cpp:193-197): an active model stores its logit and joins active_models, a zero
   // logit is stored but not active, a model that has never seen its state stores nothing -- the bank

@@ -70,6 +70,23 @@ class IndirectGroup:
     def learn(self, bit, stream=0):
         check(self.L.gmx_indirect_learn(self.h, stream, int(bit)), "gmx_indirect_learn")
 
+    def chain_forward(self, group, contexts, bit_context, predictions, active, mixer_contexts, stream=0):
+        """gmx_chain_forward: this bank's Predict and the mixers' (`group`) as one call; `predictions` / `active`
+        (indices) are the blackboard without the Indirect models.  Returns (p, mixer outputs, predictions[2K],
+        active[2K])."""
+        c = np.ascontiguousarray(contexts, np.uint32)
+        pr = np.ascontiguousarray(predictions, np.float32)
+        ac = np.ascontiguousarray(active, np.int32)
+        mc = np.ascontiguousarray(mixer_contexts, np.uint32)
+        assert c.shape == (self.K,) and pr.shape == (group.topo.n_inputs,) and mc.shape == (group.topo.n_mixers,)
+        p = C.c_float()
+        out = np.zeros(group.topo.n_mixers, np.float32)
+        pred = np.zeros(2 * self.K, np.float32)
+        act = np.zeros(2 * self.K, np.uint8)
+        check(self.L.gmx_chain_forward(self.h, group.h, stream, _vp(c), int(bit_context), _vp(pr), _vp(ac), len(ac),
+                                       _vp(mc), C.byref(p), _vp(out), _vp(pred), _vp(act)), "gmx_chain_forward")
+        return p.value, out, pred, act
+
     def run(self, batch, n_bits=None, learn=True, into=None, timed=False):
         n_bits = batch.max_bits if n_bits is None else n_bits
         ms = C.c_float(0)

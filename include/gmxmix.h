@@ -243,6 +243,19 @@ int gmx_indirect_forward(gmx_indirect* ib, int stream, const uint32_t* contexts,
                          float* predictions, uint8_t* active);
 int gmx_indirect_learn(gmx_indirect* ib, int stream, int bit);
 
+/* The Indirect models' Predict and the mixers' Predict of one bit as ONE call (predictor.cpp:366-368 runs them
+ * back to back: the last feature models, then the 33 mixers): gmx_indirect_forward followed by gmx_bank_forward
+ * with the models' predictions and active flags put into the mixers' inputs at slot_indirect / slot_run_map.
+ * When both banks answer through per-bit sessions on the same device, the Indirect models' wave hands its
+ * results to the mixers' wave itself: one host round trip instead of two.  `predictions` / `active_models`
+ * (n_active >= 0) are the blackboard WITHOUT the Indirect models (their slots are overwritten, their indices
+ * ignored); ind_predictions[2*n_models] / ind_active[2*n_models] (optional) return what gmx_indirect_forward
+ * would.  Learn with gmx_indirect_learn and gmx_bank_learn as usual.  Same floats as the two calls. */
+int gmx_chain_forward(gmx_indirect* ib, gmx_group* g, int stream, const uint32_t* ind_contexts,
+                      uint32_t bit_context, const float* predictions, const int32_t* active_models, int n_active,
+                      const uint32_t* contexts, float* p_final, float* out_all, float* ind_predictions,
+                      uint8_t* ind_active);
+
 /* Batched surface: records {contexts[n_models], bit_context, bit} of up to max_bits bits per
  * stream, results {predictions[2*n_models], active[2*n_models]} per bit. */
 int gmx_ind_batch_create(gmx_ind_batch** out, gmx_indirect* ib, uint64_t max_bits);

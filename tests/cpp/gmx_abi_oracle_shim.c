@@ -10,6 +10,7 @@
 
 struct gmx_group {
   gmxo_bank* b;
+  int n;
 };
 
 const char* gmx_strerror(int s) { return s == GMX_OK ? "ok" : s == GMX_ERR_FORMAT ? "malformed checkpoint" : "error"; }
@@ -29,6 +30,7 @@ int gmx_group_create(gmx_group** out, const gmx_topology* t, int n_streams, int 
   }
   for (int i = 0; i < t->n_skip; ++i) skip[i] = t->skip_index[i];
   gmx_group* g = (gmx_group*)calloc(1, sizeof(*g));
+  g->n = t->n_inputs;
   g->b = gmxo_create(t->n_inputs, t->n_skip, skip, t->n_mixers, layer, table, lr);
   *out = g;
   return GMX_OK;
@@ -44,6 +46,44 @@ int gmx_bank_forward(gmx_group* g, int stream, const float* predictions, const i
                      const uint32_t* contexts, float* p_final, float* out_all) {
   if (!g || stream != 0 || n_active < 0) return GMX_ERR_INVALID;
   *p_final = gmxo_predict(g->b, predictions, active, n_active, contexts, out_all);
+  return GMX_OK;
+}
+
+/* The two calls in a row, the Indirect models' results put into the mixers' inputs (the product hands them over
+ * on the device).  The Indirect side lives in gmx_abi_oracle_shim2.c, linked only into the chain builds. */
+extern int gmx_indirect_forward(gmx_indirect* ib, int stream, const uint32_t* contexts, uint32_t bit_context,
+                                float* predictions, uint8_t* active) __attribute__((weak));
+extern int gmx_shim_indirect_slots(gmx_indirect* ib, int* n, const int (**slots)[2]) __attribute__((weak));
+int gmx_chain_forward(gmx_indirect* ib, gmx_group* g, int stream, const uint32_t* ind_contexts, uint32_t bit_context,
+                      const float* predictions, const int32_t* active_models, int n_active, const uint32_t* contexts,
+                      float* p_final, float* out_all, float* ind_predictions, uint8_t* ind_active) {
+  if (!gmx_indirect_forward || !gmx_shim_indirect_slots || !ib || !g || stream != 0 || n_active < 0) return GMX_ERR_INVALID;
+  int k = 0;
+  const int (*slots)[2] = 0;
+  gmx_shim_indirect_slots(ib, &k, &slots);
+  float ip[128], pr[512];
+  uint8_t ia[128], own[512], on[512];
+  int32_t act[512];
+  int rc = gmx_indirect_forward(ib, stream, ind_contexts, bit_context, ip, ia);
+  if (rc) return rc;
+  memset(own, 0, sizeof own);
+  memset(on, 0, sizeof on);
+  memcpy(pr, predictions, (size_t)g->n * sizeof(float));
+  for (int i = 0; i < k; ++i)
+    for (int h = 0; h < 2; ++h) {
+      own[slots[i][h]] = 1;
+      pr[slots[i][h]] = ip[2 * i + h];
+      on[slots[i][h]] = ia[2 * i + h];
+    }
+  for (int i = 0; i < n_active; ++i)
+    if (!own[active_models[i]]) on[active_models[i]] = 1;
+  int na = 0;
+  for (int i = 0; i < g->n; ++i)
+    if (on[i]) act[na++] = i;
+  rc = gmx_bank_forward(g, stream, pr, act, na, contexts, p_final, out_all);
+  if (rc) return rc;
+  if (ind_predictions) memcpy(ind_predictions, ip, (size_t)2 * k * sizeof(float));
+  if (ind_active) memcpy(ind_active, ia, (size_t)2 * k);
   return GMX_OK;
 }
 

@@ -10,7 +10,15 @@
 /* ---- Indirect ---------------------------------------------------------------------------------- */
 struct gmx_indirect {
   gmxo_ind* b;
+  int n;
+  int slot[64][2];
 };
+/* for gmx_chain_forward in gmx_abi_oracle_shim.c: where the models' predictions go on the blackboard */
+int gmx_shim_indirect_slots(gmx_indirect* ib, int* n, const int (**slots)[2]) {
+  *n = ib->n;
+  *slots = ib->slot;
+  return 0;
+}
 
 int gmx_indirect_create(gmx_indirect** out, const gmx_indirect_desc* models, int n_models, const uint8_t* ns_next,
                         const uint8_t* rm_next, int n_streams, int device) {
@@ -23,6 +31,11 @@ int gmx_indirect_create(gmx_indirect** out, const gmx_indirect_desc* models, int
     lr[i] = models[i].learning_rate;
   }
   gmx_indirect* ib = (gmx_indirect*)calloc(1, sizeof *ib);
+  ib->n = n_models;
+  for (int i = 0; i < n_models; ++i) {
+    ib->slot[i][0] = models[i].slot_indirect;
+    ib->slot[i][1] = models[i].slot_run_map;
+  }
   ib->b = gmxo_ind_create(n_models, ts, lr, ns_next, rm_next);
   *out = ib;
   return GMX_OK;

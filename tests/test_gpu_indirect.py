@@ -196,6 +196,58 @@ def test_indirect_models_feed_the_mixers_inside_hbm(gpu, oracle):
         x.close()
 
 
+@pytest.mark.parametrize("mode", ["sessions", "no_indirect_session", "no_sessions"])
+def test_chain_forward_one_round_trip_per_bit(gpu, oracle, mode):
+    """gmx_chain_forward: the Indirect models' Predict and the mixers' Predict of a bit as one call -- with both
+    banks on per-bit sessions the Indirect wave hands its 82 predictions to the mixers' wave and rings its
+    mailbox itself -- against the oracle chain Indirect -> Mixer, bit by bit with Learn, a Predict without Learn
+    now and then, idle exits of both sessions, and with the fallbacks (a launch per call on either side)."""
+    import ctypes as C
+    import time
+    _, z = goldenlib.load("ind_stock41")
+    tabs = (z["ns_next"], z["rm_next"])
+    models = topology.stock_indirect()
+    K, N, T = len(models), 90, 260
+    topo = topology.stock(90)
+    slots = [(8 + 2 * i, 9 + 2 * i) for i in range(K)]
+    ig = gpu.IndirectGroup(models, *tabs, 1, slots=slots)
+    mg = gpu.MixerGroup(topo, 1)
+    ig.L.gmx_debug_indirect_use_sessions.argtypes = [C.c_void_p, C.c_int]
+    mg.L.gmx_debug_use_sessions.argtypes = [C.c_void_p, C.c_int]
+    assert ig.L.gmx_debug_indirect_use_sessions(ig.h, 0 if mode != "sessions" else 1) == 0
+    assert mg.L.gmx_debug_use_sessions(mg.h, 0 if mode == "no_sessions" else 1) == 0
+    ctx, bc, bits = oracle.ind_synth(K, T, seed=321, ctx_mod=(300, 0, 70000, 5))
+    other, act_o, mctx, _ = oracle.synth(N, 33, T, seed=654, ctx_mode=4, zero_mod=4)
+    ob = oracle.IndirectBank(models, *tabs)
+    om = oracle.Bank(N, topo.skip, topo.mixers)
+    for t in range(T):
+        if t in (90, 170):
+            time.sleep(0.06)                     # both sessions' waves have left (170: after a Predict nobody learned)
+        ip, ia = ob.predict(ctx[t], bc[t])
+        pred = other[t].copy()
+        act = np.zeros(N, np.uint8)
+        act[:8] = act_o[t, :8]
+        host_active = np.flatnonzero(act).astype(np.int32)   # the blackboard without the Indirect models
+        for i, (a, b_) in enumerate(slots):
+            pred[a], pred[b_] = ip[2 * i], ip[2 * i + 1]
+            act[a], act[b_] = ia[2 * i], ia[2 * i + 1]
+        p_ref, o_ref = om.predict(pred, np.flatnonzero(act), mctx[t])
+        stale = other[t].copy()                   # whatever stands in the Indirect slots must not matter
+        stale[8:] = 123.0
+        p, out, gp, ga = ig.chain_forward(mg, ctx[t], bc[t], stale, host_active, mctx[t])
+        assert np.array_equal(u32(gp), u32(ip)) and np.array_equal(ga, ia), t
+        assert np.array_equal(u32(out), u32(o_ref)) and np.float32(p).view(np.uint32) == np.float32(p_ref).view(np.uint32), t
+        if t % 40 != 39:
+            ig.learn(bits[t])
+            mg.learn(bits[t])
+            ob.learn(bits[t])
+            om.learn(bits[t])
+    assert ig.export(0) == ob.export()
+    assert mg.export(0) == (om.export_long(), om.export_short())
+    ig.close()
+    mg.close()
+
+
 def test_indirect_device_synth_is_the_oracles_stream(gpu, oracle):
     _, z = goldenlib.load("ind_tiny_dense")
     models = [(256, 0.02), (65536, 0.02), (32768, 0.005)]
