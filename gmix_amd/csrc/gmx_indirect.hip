@@ -262,12 +262,23 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
     const bool bit_writer = half == 0 && lane == 0;
 
     // one bit of block `cur`: Indirect::Predict, the outputs, Indirect::Learn; e_new = the entry afterwards
+    // In a byte-shaped block the states of all D bits are known at its start, so the logits of bit j+1 are read
+    // while bit j is computed -- BEFORE bit j's logit is written -- and what bit j writes is forwarded in a
+    // register when bit j+1 reads the same state (every other lane-bit on the bench's records): the LDS round
+    // trip leaves the chain of dependent operations, which is what this loop waits for.
+    float q_fwd = 0.f, p0_fwd = 0.f;  // the logits of the next bit of a shaped block: lp[e[j+1]] and lp[0]
     auto do_bit = [&](Block& cur, int j, uint32_t bit, uint32_t& e_new, auto shaped_tag) {
       constexpr bool kShaped = decltype(shaped_tag)::value;
       // ---- Indirect::Predict (indirect.cpp:28-46) ------------------------------------------
       const uint32_t st = cur.e[j];
-      const float q = lp[st];
-      const float p0 = lp[0];          // what an uninitialised nonstationary state learns at (read beside q, not behind it)
+      const bool first = !kShaped || !LEARN || j == 0;
+      const float q = first ? lp[st] : q_fwd;
+      const float p0 = first ? lp[0] : p0_fwd;  // what an uninitialised nonstationary state learns at
+      float q_raw = 0.f, p0_raw = 0.f;
+      if (kShaped && LEARN && j + 1 < D) {  // the next bit's, as they stand before this bit learns
+        q_raw = lp[cur.e[j + 1]];
+        p0_raw = lp[0];
+      }
       const bool seen = st != unseen;  // a never-seen state leaves the slot alone
       val = seen ? q : val;
       const bool act = seen && q != 0.f;  // SetLogitPrediction: a zero logit is stored, not active
@@ -304,6 +315,10 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
         e_new = nextp[2 * sn + bit];
         lp[sn] = n;
         tab[2ull * cur.idx[j]] = (uint8_t)e_new;
+        if (kShaped && j + 1 < D) {
+          q_fwd = cur.e[j + 1] == sn ? n : q_raw;
+          p0_fwd = sn == 0u ? n : p0_raw;
+        }
         if (!kShaped) {
 #pragma unroll
           for (int i = j + 1; i < D; ++i)  // the same entry again later in this block
