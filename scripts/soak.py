@@ -33,8 +33,9 @@ mask = a.shape != "single"
 b = gpu.Batch(g, a.chunk, outputs=True, mask=mask)
 # small context ranges: rows are revisited thousands of times (weight shrink every 1024th visit), come
 # back after having been written back, stay for several bits
-kw = [dict(ctx_mode=3, ctx_mod=6, zero_mod=9, bit_mode=1), dict(ctx_mode=1, ctx_mod=3, bit_mode=1), dict(ctx_mode=2, ctx_mod=40, zero_mod=5, bit_mode=1)]
-gens = [oracle.Stream(n, m, seed=1000 + s, **kw[s % 3]) for s in range(S)]
+kw = [dict(ctx_mode=3, ctx_mod=6, zero_mod=9, bit_mode=1), dict(ctx_mode=1, ctx_mod=3, bit_mode=1), dict(ctx_mode=2, ctx_mod=40, zero_mod=5, bit_mode=1),
+      dict(ctx_mode=5, ctx_mod=50, zero_mod=7, bit_mode=1)]  # the last: a real run's pattern, 4 rows moving every bit
+gens = [oracle.Stream(n, m, seed=1000 + s, **kw[s % 4]) for s in range(S)]
 if not mask:
     gens = [oracle.Stream(n, m, seed=1000 + s, ctx_mode=1, ctx_mod=5 + s, bit_mode=1) for s in range(S)]
 banks = [oracle.Bank(n, topo.skip, topo.mixers) for _ in range(S)]
