@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long parity run (not part of the test suite: minutes of CPU oracle time): S streams x T bits through
 the batched surface in chunks, every output and the final state against the oracle.
-  python scripts/soak.py [--shape wide|stock|stock-pairs|single] [--streams 3] [--bits 300000] [--chunk 7000]"""
+  python scripts/soak.py [--shape wide|stock|stock-pairs|single] [--streams 3] [--bits 300000] [--chunk 7000] [--staged 1]"""
 import argparse
 import ctypes as C
 import os
@@ -21,6 +21,7 @@ ap.add_argument("--shape", default="wide")
 ap.add_argument("--streams", type=int, default=3)
 ap.add_argument("--bits", type=int, default=300000)
 ap.add_argument("--chunk", type=int, default=7000)
+ap.add_argument("--staged", type=int, default=-1, help="stock shape: rows through the LDS images (1), lane-private (0), by stream count (-1)")
 a = ap.parse_args()
 topo = {"wide": lambda: topology.synth3(256, table0=1 << 8), "stock": lambda: topology.stock(90),
         "stock-pairs": lambda: topology.stock(90), "single": lambda: topology.single(256, 1 << 6, 0.005)}[a.shape]()
@@ -29,6 +30,9 @@ g = gpu.MixerGroup(topo, S)
 if a.shape == "stock-pairs":
     g.L.gmx_debug_stock_pairs.argtypes = [C.c_void_p, C.c_int]
     assert g.L.gmx_debug_stock_pairs(g.h, 1) == 0
+if a.staged >= 0:
+    g.L.gmx_debug_stock_staged.argtypes = [C.c_void_p, C.c_int]
+    assert g.L.gmx_debug_stock_staged(g.h, a.staged) == 0
 mask = a.shape != "single"
 b = gpu.Batch(g, a.chunk, outputs=True, mask=mask)
 # small context ranges: rows are revisited thousands of times (weight shrink every 1024th visit), come
