@@ -171,9 +171,11 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
   if (tid < NC) cst = (B + dv.state)[tid];
   auto ppm_request = [&](uint64_t nn) {
     const float* p = ppm_s + (nn < a.n_bytes ? nn : a.n_bytes - 1) * NI + tid;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(ppm_n) : "v"(p) : "memory");
+    // into an AGPR: the value is in flight from here to ppm_landed(), and an accumulation register is nothing
+    // the compiler would copy or park in scratch in between (this kernel spills a few VGPRs)
+    asm volatile("global_load_dword %0, %1, off" : "=a"(ppm_n) : "v"(p) : "memory");
   };
-  auto ppm_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(ppm_n)); };
+  auto ppm_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" : "+a"(ppm_n)); };
   if (!SESSION && (phases & 1u)) {
     ppm_request(0);
     ppm_landed();
