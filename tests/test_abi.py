@@ -101,8 +101,9 @@ def test_kernels_do_not_spill_to_scratch():
         vspill = re.findall(r"VGPRs Spill: (\d+)", report)
         assert scratch and all(s == "0" for s in scratch), (f, scratch)
         assert all(s == "0" for s in vspill), (f, vspill)
-    # gmx_lstm.hip: the default build (two workgroups per CU) keeps its one in-flight load in an AGPR and must not
-    # touch scratch; the three-per-CU tuning build (GMX_LSTM_BUILD=3) spills and is exempt
+    # gmx_lstm.hip: the default batched build (two workgroups per CU) keeps its one in-flight load in an AGPR and
+    # must not touch scratch; the three-per-CU tuning build (GMX_LSTM_BUILD=3) spills and is exempt, and so is the
+    # per-byte session, which has no asm load in flight (its inputs come from the mailbox by ordinary loads)
     out = subprocess.run(
         ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
          "-fno-gpu-flush-denormals-to-zero", "-c", os.path.join(src, "gmx_lstm.hip"), "-o", "/dev/null",
@@ -111,10 +112,10 @@ def test_kernels_do_not_spill_to_scratch():
     blocks = re.split(r"Function Name: ", report)[1:]
     seen = 0
     for blk in blocks:
-        if "gmx_lstm_kernelILi154ELi2E" in blk:
+        if "gmx_lstm_kernelILi154ELi2ELb0E" in blk:
             seen += 1
             assert re.search(r"ScratchSize \[bytes/lane\]: 0\b", blk), blk[:200]
-    assert seen == 2  # the batched kernel and the per-byte session
+    assert seen == 1
 
 
 def test_stock_kernels_leave_the_reserved_registers_alone():
