@@ -1456,29 +1456,32 @@ extern "C" int gmx_chain_forward(gmx_indirect* ib, gmx_group* g, int stream, con
     own[b >> 5] |= 1u << (b & 31);
   }
   HIPCHK(hipSetDevice(g->device));
-  std::vector<float> ip((size_t)2 * K);
-  std::vector<uint8_t> ia((size_t)2 * K);
+  float ip_[2 * GMX_IND_MAX_MODELS];  // (no allocation on a per-bit path)
+  uint8_t ia_[2 * GMX_IND_MAX_MODELS];
+  float* const ipd = ip_;
+  uint8_t* const iad = ia_;
+  const size_t n2 = (size_t)2 * K;
   if (ib->device == g->device && ib->use_sessions && g->use_sessions && group_is_stock(g) && n_active >= 0) {
     // the mixers' command first (payload in its slot, word decided, doorbell NOT rung) ...
     int rc = session_forward_prepare(g, stream, predictions, active_models, n_active, contexts, own);
     if (rc == GMX_OK) {
       GmxSession* se = g->sessions[stream];
       // ... then the Indirect models' forward, which rings it
-      rc = ind_session_forward(ib, stream, ind_contexts, bit_context, ip.data(), ia.data(), se->word, se->slot, se->mc);
+      rc = ind_session_forward(ib, stream, ind_contexts, bit_context, ipd, iad, se->word, se->slot, se->mc);
       if (rc == GMX_OK) {
         ib->fwd_done[stream] = 2;
         rc = session_forward_finish(g, stream, p_final, out_all);
         if (rc == GMX_OK) g->fwd_done[stream] = 2;
       } else {
         // the Indirect side did not take the command: ring the mixers ourselves once its inputs are whole
-        int rc2 = rc == GMX_ERR_STATE ? gmx_indirect_forward(ib, stream, ind_contexts, bit_context, ip.data(), ia.data()) : rc;
+        int rc2 = rc == GMX_ERR_STATE ? gmx_indirect_forward(ib, stream, ind_contexts, bit_context, ipd, iad) : rc;
         if (rc2 == GMX_OK) {
           GmxMbPayload* pay = &se->mc->slot[se->slot];
           for (int i = 0; i < K; ++i) {
             const int sl[2] = {ib->dev.m[i].slot_a, ib->dev.m[i].slot_b};
             for (int h = 0; h < 2; ++h) {
-              pay->pred[sl[h]] = ip[2 * i + h];
-              if (ia[2 * i + h]) pay->mask[sl[h] >> 5] = pay->mask[sl[h] >> 5] | (1u << (sl[h] & 31));
+              pay->pred[sl[h]] = ipd[2 * i + h];
+              if (iad[2 * i + h]) pay->mask[sl[h] >> 5] = pay->mask[sl[h] >> 5] | (1u << (sl[h] & 31));
             }
           }
           session_ring(se);
@@ -1488,15 +1491,15 @@ extern "C" int gmx_chain_forward(gmx_indirect* ib, gmx_group* g, int stream, con
         rc = rc2;
       }
       if (rc == GMX_OK) {
-        if (ind_predictions) memcpy(ind_predictions, ip.data(), ip.size() * 4);
-        if (ind_active) memcpy(ind_active, ia.data(), ia.size());
+        if (ind_predictions) memcpy(ind_predictions, ipd, n2 * 4);
+        if (ind_active) memcpy(ind_active, iad, n2);
       }
       return rc;
     }
     if (rc != GMX_ERR_STATE) return rc;  // GMX_ERR_STATE: no session slot for the mixers, the two calls instead
   }
   // the two calls, the host in between
-  int rc = gmx_indirect_forward(ib, stream, ind_contexts, bit_context, ip.data(), ia.data());
+  int rc = gmx_indirect_forward(ib, stream, ind_contexts, bit_context, ipd, iad);
   if (rc) return rc;
   std::vector<float> pr(predictions, predictions + t.n);
   std::vector<int32_t> act;
@@ -1511,14 +1514,14 @@ extern "C" int gmx_chain_forward(gmx_indirect* ib, gmx_group* g, int stream, con
   for (int i = 0; i < K; ++i) {
     const int sl[2] = {ib->dev.m[i].slot_a, ib->dev.m[i].slot_b};
     for (int h = 0; h < 2; ++h) {
-      pr[sl[h]] = ip[2 * i + h];
-      if (ia[2 * i + h]) act.push_back(sl[h]);
+      pr[sl[h]] = ipd[2 * i + h];
+      if (iad[2 * i + h]) act.push_back(sl[h]);
     }
   }
   rc = gmx_bank_forward(g, stream, pr.data(), act.data(), (int)act.size(), contexts, p_final, out_all);
   if (rc) return rc;
-  if (ind_predictions) memcpy(ind_predictions, ip.data(), ip.size() * 4);
-  if (ind_active) memcpy(ind_active, ia.data(), ia.size());
+  if (ind_predictions) memcpy(ind_predictions, ipd, n2 * 4);
+  if (ind_active) memcpy(ind_active, iad, n2);
   return GMX_OK;
 }
 
