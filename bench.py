@@ -44,17 +44,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 WORKLOADS = {
     # name: (topology, ctx_mode, default streams per GPU, default bits per stream per step, target total bits,
     #        one-core sample bits, description)
-    "single": ("single", 0, 4096, 512, 100_000_000, 20_000_000,
+    "single": ("single", 0, 4096, 1024, 100_000_000, 20_000_000,
                "configs[1]: synthetic 256-input 1-layer mixer (1 mixer, 2^16-row gate table), random logits, forward+update"),
     "synth3": ("synth3", 0, 2048, 512, 8_000_000, 300_000,
                "synthetic 256-input 3-layer 24/8/1 bank (2^12-row layer-0 tables), new gate rows every bit, forward+update"),
-    "stock": ("stock", 0, 1024, 256, 4_000_000, 400_000,
+    "stock": ("stock", 0, 1024, 1024, 8_000_000, 400_000,
               "stock 24/8/1 topology of Predictor::AddMixers, 90 inputs, synthetic records, forward+update"),
-    "stock_held": ("stock", 2, 1024, 256, 16_000_000, 800_000,
+    "stock_held": ("stock", 2, 1024, 1024, 16_000_000, 800_000,
                    "stock 24/8/1 topology of Predictor::AddMixers, 90 inputs, synthetic records, gate contexts redrawn every 8th bit, forward+update"),
-    "stock_fresh": ("stock", 0, 1024, 256, 8_000_000, 400_000,
+    "stock_fresh": ("stock", 0, 1024, 1024, 8_000_000, 400_000,
                     "stock 24/8/1 topology of Predictor::AddMixers, 90 inputs, synthetic records, every gate context new every bit, forward+update"),
-    "stock_real": ("stock", 4, 1024, 256, 8_000_000, 800_000,
+    "stock_real": ("stock", 4, 1024, 1024, 8_000_000, 800_000,
                    "stock 24/8/1 topology of Predictor::AddMixers, 90 inputs, synthetic records with a real run's "
                    "row-change pattern: all 33 gate contexts redrawn at byte boundaries, the four bit-level ones "
                    "(2 layer-0, 2 layer-1) every bit, forward+update"),
@@ -297,7 +297,7 @@ def main():
                     help="independent streams per GPU (each owns a dense 64.5 MiB gate table: 3072 = 194 GiB of HBM)")
     ap.add_argument("--bits", type=int, default=None, help="bits per stream per step")
     ap.add_argument("--config", default="single", choices=sorted(WORKLOADS))
-    ap.add_argument("--ring", type=int, default=4, help="distinct record batches cycled through")
+    ap.add_argument("--ring", type=int, default=2, help="distinct record batches cycled through")
     ap.add_argument("--variant", type=int, default=0,
                     help="tuning: lanes per stream of the single-mixer kernel (0 = library default)")
     ap.add_argument("--ctx-mode", type=int, default=None,

@@ -3,11 +3,11 @@
 R=${1:-2}
 cd "$(dirname "$0")/.."
 S="--no-cpu-baseline --no-also"
-python3 scripts/pmc_summary.py bench_single $R gmx_single_kernel 4096 512 3080 "python bench.py --config single --steps 12 $S" 0 > /dev/null
+python3 scripts/pmc_summary.py bench_single $R gmx_single_kernel 4096 1024 3080 "python bench.py --config single --steps 12 $S" 0 > /dev/null
 python3 scripts/pmc_summary.py synth3 $R gmx_wide_kernel 2048 512 54608 "python bench.py --config synth3 --steps 6 $S" 0 > /dev/null
-python3 scripts/pmc_summary.py stock_held $R gmx_stock_kernel 1024 256 3193 "python bench.py --config stock_held --steps 8 $S" 2 > /dev/null
-python3 scripts/pmc_summary.py stock_real $R gmx_stock_kernel 1024 256 4943 "python bench.py --config stock_real --steps 8 $S" 4 > /dev/null
-python3 scripts/pmc_summary.py stock_fresh $R gmx_stock_kernel 1024 256 22072 "python bench.py --config stock_fresh --steps 8 $S" 0 > /dev/null
+python3 scripts/pmc_summary.py stock_held $R gmx_stock_kernel 1024 1024 3193 "python bench.py --config stock_held --steps 8 $S" 2 > /dev/null
+python3 scripts/pmc_summary.py stock_real $R gmx_stock_kernel 1024 1024 4943 "python bench.py --config stock_real --steps 8 $S" 4 > /dev/null
+python3 scripts/pmc_summary.py stock_fresh $R gmx_stock_kernel 1024 1024 22072 "python bench.py --config stock_fresh --steps 8 $S" 0 > /dev/null
 python3 scripts/pmc_summary.py indirect $R gmx_indirect_kernel 256 4096 743 "python scripts/bench_indirect.py" 0 > /dev/null
 cp gpurun_out/indirect_bench.json profiles/r$(printf %02d $R)_indirect_bench.json
 cp gpurun_out/real_trace.json profiles/r$(printf %02d $R)_real_trace_bench.json
@@ -16,7 +16,7 @@ python3 - "$R" <<'PY'
 import csv, glob, collections, json, sys
 R = int(sys.argv[1])
 out = []
-for tag, S, T in (("w1024", 1024, 256), ("w256", 256, 256), ("w1", 1, 8192)):
+for tag, S, T in (("w1024", 1024, 1024), ("w256", 256, 1024), ("w1", 1, 8192)):
     acc = collections.defaultdict(list)
     for f in glob.glob(f"gpurun_out/prof_{tag}/waits/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
