@@ -1,5 +1,6 @@
-"""BASELINE.json configs[1] at the bench's full size (4096 streams x 512 bits, 258 GiB of gate
-tables) and the 256-input 24/8/1 bank at bench scale (1024 streams x 512 bits: one wave on every SIMD; bench.py runs two) through properties that do not need the oracle to run 1.5 M bits: a launch split in two
+"""BASELINE.json configs[1] at the bench's full stream count (4096 streams, 258 GiB of gate
+tables; 512 bits per launch here, bench.py times 1024) and the 256-input 24/8/1 bank at bench scale
+(1024 streams: one wave on every SIMD; bench.py runs two) through properties that do not need the oracle to run 1.5 M bits: a launch split in two
 gives the same floats and the same banks; sampled streams equal the oracle run on the same seed;
 streams do not leak into each other."""
 import numpy as np
@@ -9,7 +10,7 @@ from gmix_amd import topology
 
 pytestmark = pytest.mark.gpu
 
-S, T = 4096, 512   # bench.py's defaults for --config single
+S, T = 4096, 512   # bench.py's stream count for --config single; half its bits per launch
 GOLD = 0x9E3779B97F4A7C15
 SEED = 0x1234567
 
