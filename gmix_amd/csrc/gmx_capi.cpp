@@ -1448,7 +1448,7 @@ extern "C" int gmx_chain_forward(gmx_indirect* ib, gmx_group* g, int stream, con
   if (n_active > 0 && !active_models) return GMX_ERR_INVALID;
   const GmxTopoDev& t = g->topo;
   const int K = ib->dev.k;
-  uint32_t own[4] = {0, 0, 0, 0};  // the active-mask bits of the Indirect models' slots
+  uint32_t own[GMX_MAX_INPUTS / 32] = {0};  // the active-mask bits of the Indirect models' slots
   for (int i = 0; i < K; ++i) {
     const int a = ib->dev.m[i].slot_a, b = ib->dev.m[i].slot_b;
     if (a < 0 || a >= t.n || b < 0 || b >= t.n) return GMX_ERR_INVALID;
@@ -1487,6 +1487,11 @@ extern "C" int gmx_chain_forward(gmx_indirect* ib, gmx_group* g, int stream, con
           session_ring(se);
           rc2 = session_forward_finish(g, stream, p_final, out_all);
           if (rc2 == GMX_OK) g->fwd_done[stream] = 2;
+        } else {
+          // the prepared command still goes (it carries the learn gmx_bank_learn noted, and the mailbox
+          // protocol expects an answer to the word it was given); its forward is not one to learn from
+          session_ring(se);
+          if (session_forward_finish(g, stream, nullptr, nullptr) == GMX_OK) se->fwd_live = false;
         }
         rc = rc2;
       }

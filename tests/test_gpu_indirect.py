@@ -248,6 +248,42 @@ def test_chain_forward_one_round_trip_per_bit(gpu, oracle, mode):
     mg.close()
 
 
+def test_chain_forward_into_a_wide_bank(gpu, oracle):
+    """gmx_chain_forward with mixers that are not the stock shape (256 inputs, the Indirect models' slots beyond
+    input 128): the two calls with the host in between, same floats as the oracle chain."""
+    _, z = goldenlib.load("ind_tiny_dense")
+    tabs = (z["ns_next"], z["rm_next"])
+    models = [(256, 0.02), (65536, 0.02), (32768, 0.005)]
+    K, N, T = len(models), 256, 48
+    topo = topology.synth3(N, table0=1 << 8)
+    slots = [(250, 255), (128, 131), (5, 200)]
+    ig = gpu.IndirectGroup(models, *tabs, 1, slots=slots)
+    mg = gpu.MixerGroup(topo, 1)
+    ctx, bc, bits = oracle.ind_synth(K, T, seed=77, ctx_mod=(50, 0, 3000, 7))
+    other, act_o, mctx, _ = oracle.synth(N, topo.n_mixers, T, seed=78, ctx_mode=1, ctx_mod=97, zero_mod=5)
+    ob = oracle.IndirectBank(models, *tabs)
+    om = oracle.Bank(N, topo.skip, topo.mixers)
+    own = sorted(x for ab in slots for x in ab)
+    for t in range(T):
+        ip, ia = ob.predict(ctx[t], bc[t])
+        pred = other[t].copy()
+        act = act_o[t].astype(np.uint8).copy()
+        host_active = np.flatnonzero(act).astype(np.int32)   # lists the Indirect slots too: they are ignored
+        act[own] = 0
+        for i, (a, b_) in enumerate(slots):
+            pred[a], pred[b_] = ip[2 * i], ip[2 * i + 1]
+            act[a], act[b_] = ia[2 * i], ia[2 * i + 1]
+        p_ref, o_ref = om.predict(pred, np.flatnonzero(act), mctx[t])
+        p, out, gp, ga = ig.chain_forward(mg, ctx[t], bc[t], other[t], host_active, mctx[t])
+        assert np.array_equal(u32(gp), u32(ip)) and np.array_equal(ga, ia), t
+        assert np.array_equal(u32(out), u32(o_ref)) and np.float32(p).view(np.uint32) == np.float32(p_ref).view(np.uint32), t
+        ig.learn(bits[t]); mg.learn(bits[t]); ob.learn(bits[t]); om.learn(bits[t])
+    assert ig.export(0) == ob.export()
+    assert mg.export(0) == (om.export_long(), om.export_short())
+    ig.close()
+    mg.close()
+
+
 def test_indirect_device_synth_is_the_oracles_stream(gpu, oracle):
     _, z = goldenlib.load("ind_tiny_dense")
     models = [(256, 0.02), (65536, 0.02), (32768, 0.005)]
