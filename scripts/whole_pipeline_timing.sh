@@ -9,7 +9,7 @@ W=$(mktemp -d)
 cat SURVEY.md DESIGN.md INTEGRATION.md PAPERS.md SNIPPETS.md 2>/dev/null | head -c $N > $W/in
 echo "input: $(wc -c < $W/in) bytes of text; host: $(grep -m1 'model name' /proc/cpuinfo | cut -d: -f2)"
 for exe in gmix_strict gmix_gpu gmix_chain; do
-  [ "$exe" = gmix_chain ] && [ "$N" -gt 20000 ] && head -c 20000 $W/in > $W/in_c && IN=$W/in_c || IN=$W/in
+  IN=$W/in
   mkdir -p $W/$exe && cd $W/$exe
   s=$(date +%s.%N)
   timeout -k 10 900 $OLDPWD/oracle/_ref/$exe -c $IN $W/$exe/out > /dev/null 2>&1
@@ -19,4 +19,10 @@ for exe in gmix_strict gmix_gpu gmix_chain; do
   python3 -c "import sys; n=$(wc -c < $IN); t=$e-$s; print('%-12s rc %d  %7d bytes -> %6d  %.1f s  %.0f bits/s  %.1f us/bit  md5 %s' % ('$exe', $rc, n, $(wc -c < $W/$exe/out), t, 8*n/t, t/(8*n)*1e6, '$(md5sum < $W/$exe/out | cut -c1-12)'))"
 done
 cmp $W/gmix_strict/out $W/gmix_gpu/out && echo "gmix_gpu output == gmix_strict output"
+cmp $W/gmix_strict/out $W/gmix_chain/out && echo "gmix_chain output == gmix_strict output"
+# and back: the stock build decodes what the device chain encoded, the device chain what the stock build encoded
+(cd $W/gmix_strict && timeout -k 10 900 $OLDPWD/oracle/_ref/gmix_strict -d $W/gmix_chain/out $W/back_s > /dev/null 2>&1)
+cmp $W/in $W/back_s && echo "gmix_strict -d (gmix_chain -c (input)) == input"
+(cd $W/gmix_chain && timeout -k 10 900 $OLDPWD/oracle/_ref/gmix_chain -d $W/gmix_strict/out $W/back_c > /dev/null 2>&1)
+cmp $W/in $W/back_c && echo "gmix_chain -d (gmix_strict -c (input)) == input"
 rm -rf $W
