@@ -190,7 +190,40 @@ __global__ void gmx_math_range_kernel(uint64_t lo, uint64_t count, int what,
        i += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t u = (uint32_t)(lo + i);
     const float v = gmx_u2f(u);
-    float r = what == 0 ? gmx_expf(v) : (what == 1 ? gmx_logistic(v) : gmx_squash_clamp(v));
+    float r;
+    if (what == 3) {
+      // the wave-level logistic of gmx_stock.hip (short way where a whole wave has |v| < 64): the caller
+      // compares the checksums with those of what == 1
+      r = gmx_wave_logistic(v, gmx_exp2f_tab);
+    } else if (what == 4) {
+      // the short row-age division against the general one on a pair of counters below 2^32 made from i:
+      // small pairs exhaustively (i < 2^24: 4096 x 4096), then hashed ones with the edges mixed in; the
+      // checksums count the differing bit patterns
+      const uint64_t i64 = lo + i;
+      uint32_t ca, cb;
+      if (i64 < (1ull << 24)) {
+        ca = (uint32_t)(i64 & 4095u);
+        cb = (uint32_t)(i64 >> 12) + 1u;
+      } else {
+        uint64_t h = i64 * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+        h *= 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 32;
+        cb = (uint32_t)h >> ((h >> 59) & 31u);
+        if (cb == 0) cb = 0xffffffffu;
+        ca = (uint32_t)(h >> 32) >> ((h >> 54) & 31u);
+        if ((i64 & 7u) == 0) ca = ca % cb;          // the reference's case: row.steps <= max_steps_
+        if ((i64 & 1023u) == 1) ca = cb;
+        if ((i64 & 1023u) == 2) ca = cb - 1u;
+      }
+      const double q_short = gmx_row_age_short(ca, cb), q_gen = (double)ca / (double)cb;
+      const bool bad = gmx_d2u(q_short) != gmx_d2u(q_gen);
+      x ^= bad ? i64 + 1 : 0;
+      sacc += bad ? 1 : 0;
+      continue;
+    } else {
+      r = what == 0 ? gmx_expf(v) : (what == 1 ? gmx_logistic(v) : gmx_squash_clamp(v));
+    }
     uint32_t rb = gmx_f2u(r);
     if (r != r) rb = 0x7fc00000u;  // all NaNs alike
     x ^= (unsigned long long)rb * 0x9E3779B97F4A7C15ull + u;

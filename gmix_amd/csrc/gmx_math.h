@@ -79,16 +79,14 @@ GMX_HD double gmx_u2d(uint64_t u) {
 }
 
 // expf as glibc 2.27+ computes it on FMA-capable x86-64 (see file header); `tab` is
-// gmx_exp2f_tab or a copy of it.
-GMX_HD float gmx_expf_tab(float x, const uint64_t* tab) {
+// gmx_exp2f_tab or a copy of it.  First the main path alone: expf(x) for |x| < 88 (e_expf.c takes
+// none of its special cases there).
+GMX_HD float gmx_expf_main(float x, const uint64_t* tab) {
   const double kShift = 0x1.8p+52;
   const double kInvLn2N = 0x1.71547652b82fep+0 * 32;
   const double kC0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32;
   const double kC1 = 0x1.ebfce50fac4f3p-3 / 32 / 32;
   const double kC2 = 0x1.62e42ff0c52d6p-1 / 32;
-  const uint32_t ux = gmx_f2u(x);
-  const uint32_t abstop = (ux >> 20) & 0x7ff;
-  // main path (meaningful for |x| < ~104; harmless garbage beyond, overridden below)
   const double xd = (double)x;
   double kd = gmx_fma(kInvLn2N, xd, kShift);    // round(x*N/ln2) in the low mantissa bits
   const uint64_t ki = gmx_d2u(kd);
@@ -101,7 +99,14 @@ GMX_HD float gmx_expf_tab(float x, const uint64_t* tab) {
   double y = gmx_fma(kC2, r, 1.0);
   y = gmx_fma(z, r2, y);
   y = y * s;
-  float res = (float)y;
+  return (float)y;
+}
+
+GMX_HD float gmx_expf_tab(float x, const uint64_t* tab) {
+  const uint32_t ux = gmx_f2u(x);
+  const uint32_t abstop = (ux >> 20) & 0x7ff;
+  // main path (meaningful for |x| < ~104; harmless garbage beyond, overridden below)
+  float res = gmx_expf_main(x, tab);
   // special cases of e_expf.c, in its order of precedence (last assignment wins here)
   const bool big = abstop >= 0x42b;                               // |x| >= 88 or NaN
   res = (big && x < -0x1.9d1d9ep6f) ? gmx_u2f(1u) : res;          // 0x1.4p-75f squared = 2^-149
@@ -119,6 +124,67 @@ GMX_HD float gmx_logistic_tab(float p, const uint64_t* tab) {
   return 1.0f / (1.0f + gmx_expf_tab(-p, tab));
 }
 GMX_HD float gmx_logistic(float p) { return gmx_logistic_tab(p, gmx_exp2f_tab); }
+
+// ---- wave-level short ways (gfx950 only; used by gmx_stock.hip) ---------------------------------
+#if defined(__HIPCC__)
+// Sigmoid::Logistic of the wave's outputs (mixer.cpp:113-122) and the row-age ratio (1.0 * row.steps) / max_steps_
+// of mixer.cpp:112, together and in one basic block: neither needs the other, and the ratio's double-precision
+// chain fills the wait for expf's table entry.  The wave issues every instruction at full price, so both take
+// the short way whenever EVERY lane allows it (anything else: the general expressions, same results):
+//  * |p| < 64: none of e_expf.c's special cases applies (they start at 88), and d = 1 + e lies in [1, 2^93),
+//    where the IEEE division 1.0f / d as the compiler expands it (2 x v_div_scale, v_rcp, Newton steps,
+//    v_div_fmas, v_div_fixup) scales nothing and fixes nothing up: the same v_rcp / fma sequence without those steps;
+//  * both counters below 2^32: the conversions to double are exact from the low words, and the double
+//    division's scaling / fix-up steps are identities for integers of that size (0 / b is +0 either way;
+//    max_steps_ is never 0: it starts at 1 and only grows, mixer.cpp:8, :126-128).
+// gmx_debug_math_range (what = 3, 4) compares the short ways with the general ones over all floats / over
+// 2^32 counter pairs on the device.
+__device__ __forceinline__ bool gmx_wave_short_math(float p, uint64_t rs, uint64_t ms) {
+  const uint32_t abstop = (gmx_f2u(p) >> 20) & 0x7ffu;
+  return __ballot(abstop >= 0x428u || (uint32_t)((rs | ms) >> 32) != 0u) == 0;
+}
+__device__ __forceinline__ float gmx_logistic_short(float p, const uint64_t* tab) {
+  const float d = 1.0f + gmx_expf_main(-p, tab);
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+  const float r1 = __builtin_fmaf(e0, r0, r0);
+  const float e1 = __builtin_fmaf(-d, r1, 1.0f);  // the quotient starts as 1.0f * r1
+  const float q1 = __builtin_fmaf(e1, r1, r1);
+  const float e2 = __builtin_fmaf(-d, q1, 1.0f);
+  return __builtin_fmaf(e2, r1, q1);
+}
+__device__ __forceinline__ double gmx_row_age_short(uint64_t rs, uint64_t ms) {
+  const double a = (double)(uint32_t)rs, b = (double)(uint32_t)ms;
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  const double q = a * r;
+  e = __builtin_fma(-b, q, a);
+  return __builtin_fma(e, r, q);
+}
+__device__ __forceinline__ float gmx_wave_logistic_and_age(float p, const uint64_t* tab, uint64_t rs, uint64_t ms,
+                                                        double& age) {
+  if (gmx_wave_short_math(p, rs, ms)) {
+    age = gmx_row_age_short(rs, ms);
+    return gmx_logistic_short(p, tab);
+  }
+  age = (double)rs / (double)ms;
+  return gmx_logistic_tab(p, tab);
+}
+
+// Either alone (the per-bit kernels learn in a later command than they predict).
+__device__ __forceinline__ float gmx_wave_logistic(float p, const uint64_t* tab) {
+  double unused;
+  return gmx_wave_logistic_and_age(p, tab, 0, 1, unused);
+}
+__device__ __forceinline__ double gmx_wave_row_age(uint64_t rs, uint64_t ms) {
+  if (__ballot((uint32_t)((rs | ms) >> 32) != 0u) == 0) return gmx_row_age_short(rs, ms);
+  return (double)rs / (double)ms;
+}
+
+#endif  // __HIPCC__
 
 // Final squash of Predictor::Predict (predictor.cpp:369-375): clamp to [1e-4f, 1-1e-4f].
 GMX_HD float gmx_clamp_prob(float prob) {

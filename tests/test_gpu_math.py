@@ -54,3 +54,19 @@ def test_device_logistic_exhaustive_checksum(gpu):
         assert L.gmx_debug_math_range(0, 0, 1 << 32, what, dev) == 0
         H.gmx_host_math_range(0, 1 << 32, what, host)
         assert (dev[0], dev[1]) == (host[0], host[1]), what
+
+
+def test_wave_level_short_ways_equal_the_general_expressions(gpu):
+    """gmx_stock.hip's logistic and row-age division take shorter instruction sequences when a whole wave is in
+    range (gmx_math.h, gmx_wave_*): the logistic over all 2^32 inputs folds to the same checksum as the general
+    function (which the test above pins to libm), and the short double division equals the compiler's on 4096 x 4096
+    small counter pairs and 2^32 hashed ones (what = 4 counts the differing results)."""
+    L = gpu._lib.lib()
+    gen = (C.c_ulonglong * 2)()
+    short = (C.c_ulonglong * 2)()
+    assert L.gmx_debug_math_range(0, 0, 1 << 32, 1, gen) == 0
+    assert L.gmx_debug_math_range(0, 0, 1 << 32, 3, short) == 0
+    assert (short[0], short[1]) == (gen[0], gen[1])
+    bad = (C.c_ulonglong * 2)()
+    assert L.gmx_debug_math_range(0, 0, (1 << 32) + (1 << 24), 4, bad) == 0
+    assert (bad[0], bad[1]) == (0, 0), "short row-age division differs on %d pairs (xor of 1 + their indices: %d)" % (bad[1], bad[0])
