@@ -26,12 +26,12 @@ Hazards honoured by construction (gfx940/gfx950; the spacing hipcc itself keeps)
 """
 import os
 
-TB, XB, WB, AB, O0, O1 = 44, 48, 140, 140, 64, 88
+TB, XB, WB, AB, O0, O1 = 44, 48, 140, 140, 70, 94
 N, L0, L1, M = 90, 24, 8, 33
 NQX = (N + 3) // 4   # 23 quads of inputs
 NQW = 29             # quads of a layer-0 row (113 weights)
 NQA = 9              # quads of a layer-1 / final row that hold weights (33 of the 64 floats stored)
-RESERVED = {"v": (44, 255), "a": (44, 255), "s": (64, 95)}
+RESERVED = {"v": (44, 255), "a": (44, 255), "s": (70, 101)}
 
 
 def W(j):
@@ -138,7 +138,7 @@ def adopt(first, last):
     return under_mask([f"v_accvgpr_read_b32 {W(j)}, a{AB + j}" for j in range(4 * first, 4 * last)])
 
 
-SP = 64        # s64..s71: four rotating SGPR pairs for row addresses (O0/O1 are dead outside forward..update)
+SP = 70        # s70..s77: four rotating SGPR pairs for row addresses (O0/O1 are dead outside forward..update)
 STG = 44       # a44..a175: 33 quads, the write-back's way from the image to the stores
 PITCH = 528    # bytes between rows of a staging image: 33 quads, odd, so transposed accesses do not conflict
 
@@ -177,7 +177,7 @@ def fetch_rows(NR=M):
 
 def fetch_sparse():
     """The same for a few rows: a loop over the set bits of %[m] (64-bit, consumed), 11 instructions a row.
-    s64..s68 are free here (O0 is dead outside forward..update).  The six scalar instructions between the
+    s70..s74 are free here (O0 is dead outside forward..update).  The six scalar instructions between the
     second v_readlane and the LDS-DMA are its wait states (v_readlane -> VMEM address: 5; m0 -> LDS-DMA: 1)."""
     return [f"s_mov_b32 s{SP + 3}, 0xffff", "s_mov_b64 %[sv], exec", "s_mov_b32 %[sm0], m0", "s_mov_b32 exec_hi, 0",
             f"s_movk_i32 s{SP + 4}, {PITCH}", "s_nop 0",  # the loop starts at 4 mod 8: nothing in it straddles
@@ -230,22 +230,30 @@ def from_image(first, last):
 
 
 def load_x(l, consume):
-    """Broadcast-read the 23 input quads from LDS into X, at most `depth` reads in flight
-    (lgkmcnt is a 4-bit counter); consume(q) emits the work that needs quad q."""
-    depth = 8
+    """Broadcast-read the 23 input quads from LDS into X; consume(q) emits the work that needs quad q.
+    Every instruction costs a lone wave its 4-cycle issue slot, an s_waitcnt that is already satisfied
+    included (scripts/ubench/issue_ubench.hip), so the reads are waited for four quads at a time: 12 reads
+    go out at once (lgkmcnt is a 4-bit counter: never more than 15 in flight), then each group of four
+    costs one wait and is followed by the next four reads."""
+    group, ahead = 4, 12
     l.append("s_waitcnt lgkmcnt(0)")
-    for q in range(min(depth, NQX)):
+    issued = min(ahead, NQX)
+    for q in range(issued):
         l.append(f"ds_read_b128 {X4(q)}, %[xaddr] offset:{16 * q}")
-    for q in range(NQX):
-        issued = min(NQX, q + depth)
-        l.append(f"s_waitcnt lgkmcnt({issued - q - 1})")
-        if q + depth < NQX:
-            l.append(f"ds_read_b128 {X4(q + depth)}, %[xaddr] offset:{16 * (q + depth)}")
-        consume(q)
+    for g0 in range(0, NQX, group):
+        g1 = min(NQX, g0 + group)
+        l.append(f"s_waitcnt lgkmcnt({issued - g1})")
+        more = min(NQX, issued + group)
+        for q in range(issued, more):
+            l.append(f"ds_read_b128 {X4(q)}, %[xaddr] offset:{16 * q}")
+        issued = more
+        for q in range(g0, g1):
+            consume(q)
 
 
-def chain_l0(l, with_loads=True):
-    """layer 0, inputs 0..89 (mixer.cpp:56-59): acc = acc + x*w, left to right"""
+def chain_l0(l, with_loads=True, from_zero=False):
+    """layer 0, inputs 0..89 (mixer.cpp:56-59): acc = acc + x*w, left to right (from_zero: the first sum is
+    0.0f + x*w with the constant as an operand, acc need not be cleared first)"""
     def consume(q):
         # products two at a time (same IEEE multiply), the sum strictly one after the other
         for h in range(2):
@@ -253,7 +261,7 @@ def chain_l0(l, with_loads=True):
             if j < N:
                 t = TB + 2 * ((j // 2) % 2)
                 l.append(f"v_pk_mul_f32 v[{t}:{t + 1}], {X2(j)}, {W2(j)}")
-                l.append(f"v_add_f32 %[acc], %[acc], v{t}")
+                l.append(f"v_add_f32 %[acc], {'0' if from_zero and j == 0 else '%[acc]'}, v{t}")
                 if j + 1 < N:
                     l.append(f"v_add_f32 %[acc], %[acc], v{t + 1}")
     if with_loads:
@@ -268,21 +276,23 @@ def forward():
     part in a step sees a zero weight there (the stored padding beyond weight_size; a row never
     learned is all zeros), so `acc + o*0` leaves it alone -- exact as long as every value is
     finite, which the kernel checks afterwards (else it redoes the bit with forward_exact)."""
-    l = ["v_mov_b32 %[acc], 0", "v_mov_b32 %[a1], 0"]
-    chain_l0(l)
+    l = []
+    chain_l0(l, from_zero=True)
     # layer-0 cascade (mixer.cpp:60-64) merged with the sums of layer 1 / final over the
-    # layer-0 outputs (mixer.cpp:66-68, 82-84): O0(i) is read once and feeds both
+    # layer-0 outputs (mixer.cpp:66-68, 82-84): O0(i) is read once and feeds both.  The hazard slots
+    # (VALU -> v_readlane of its result: 1 wait state; v_readlane -> VALU reading the SGPR: 2) hold
+    # useful instructions where there are any -- a nop costs a lone wave a full issue slot per wait state.
     for i in range(L0):
         if i >= 1:
             l.append(f"v_mul_f32 %[t1], s{O0 + i - 1}, {W(i - 1)}")
         else:
-            l.append("s_nop 0")
+            l.append("s_mov_b32 vcc_hi, 0")  # (for the layer-1 selects below)
         l.append(f"v_readlane_b32 s{O0 + i}, %[acc], {i}")
         if i >= 1:
             l.append("v_add_f32 %[a1], %[a1], %[t1]")
-            l.append("s_nop 0")
         else:
-            l.append("s_nop 1")
+            l.append("v_mov_b32 %[a1], 0")
+        l.append("s_nop 0")
         if i < L0 - 1:
             l.append(f"v_mul_f32 %[t0], s{O0 + i}, {W(N + i)}")
             l.append("v_add_f32 %[acc], %[acc], %[t0]")
@@ -291,20 +301,21 @@ def forward():
     # From here on %[a1] is the running sum of lanes 24..32 (garbage in the layer-0 lanes, whose
     # outputs stay in %[acc]).  Layer-1 cascade, each mixer's skip input closing its chain
     # (mixer.cpp:69-80); lane 32, the final mixer, collects the layer-1 outputs on the way
-    # (mixer.cpp:85-90).
-    l.append("s_mov_b32 vcc_hi, 0")
+    # (mixer.cpp:85-90).  The skip product of the NEXT mixer (the final mixer's after the last,
+    # mixer.cpp:91-97; weight 32 of the layer-1 lanes is padding) fills one of the two wait states
+    # behind each v_readlane; it goes to the chain's product registers, which are free by now.
+    sk = lambda i: f"v{TB + (i % 2)}"
+    l.append(f"v_mul_f32 {sk(0)}, %[vskip], {W(L0)}")
     for i in range(L1):
-        l.append(f"v_mul_f32 %[t0], %[vskip], {W(L0 + i)}")
-        l.append("v_add_f32 %[t1], %[a1], %[t0]")
+        l.append(f"v_add_f32 %[t1], %[a1], {sk(i)}")
         l.append(f"s_mov_b32 vcc_lo, {hex(1 << (L0 + i))}")
         l.append(f"v_readlane_b32 s{O1 + i}, %[t1], {L0 + i}")
-        l.append("s_nop 1")
+        l.append(f"v_mul_f32 {sk(i + 1)}, %[vskip], {W(L0 + i + 1)}")
+        l.append("s_nop 0")
         l.append(f"v_mul_f32 %[t0], s{O1 + i}, {W(L0 + i)}")
         l.append("v_add_f32 %[t0], %[a1], %[t0]")
         l.append("v_cndmask_b32 %[a1], %[t0], %[t1], vcc")
-    # the final mixer's skip input (mixer.cpp:91-97); weight 32 of the layer-1 lanes is padding
-    l.append(f"v_mul_f32 %[t0], %[vskip], {W(L0 + L1)}")
-    l.append("v_add_f32 %[a1], %[a1], %[t0]")
+    l.append(f"v_add_f32 %[a1], %[a1], {sk(L1)}")
     l.append("s_mov_b32 vcc_lo, 0xffffff")
     l.append("v_cndmask_b32 %[acc], %[a1], %[acc], vcc")
     return l

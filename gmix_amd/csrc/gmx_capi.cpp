@@ -42,7 +42,7 @@ hipError_t gmx_launch_bank_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* ar
                                   unsigned stride0, hipStream_t stream);
 hipError_t gmx_bank_kernel_set_lds(unsigned lds_bytes);
 hipError_t gmx_launch_stock_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_streams,
-                                   unsigned lds_bytes, int has_mask, int staged, hipStream_t stream);
+                                   unsigned lds_bytes, int has_mask, int staged, int pow2_tables, hipStream_t stream);
 hipError_t gmx_launch_single_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_inputs,
                                     int variant, hipStream_t stream);
 hipError_t gmx_launch_wide_kernel(const GmxTopoDev* tp_dev, const GmxRunArgs* args, int n_streams, int has_mask,
@@ -580,6 +580,13 @@ extern "C" int gmx_group_timer_stop(gmx_group* g, float* ms) {
 // second factor (mixer.cpp:112) is IEEE double arithmetic and stays on the device.
 static float decay_base(uint64_t steps) { return (float)(0.9 / pow(0.0000001 * steps + 0.8, 0.8)); }
 
+// Every gate table a power of two (the reference's are): the stock kernel's compile-time "plain" build indexes with a mask.
+static int topo_tables_pow2(const GmxTopoDev& t) {
+  for (int j = 0; j < t.m; ++j)
+    if (t.mx[j].table_size == 0 || (t.mx[j].table_size & (t.mx[j].table_size - 1u)) != 0) return 0;
+  return 1;
+}
+
 #include "gmx_session.inc"
 
 static const uint32_t kDecayAmbCap = 4096;
@@ -753,7 +760,7 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
     HIPCHK(gmx_launch_wide_kernel(g->topo_dev, &a, ns, a.mask != nullptr, g->topo.n, g->stream));
   else if (stock)
     HIPCHK(gmx_launch_stock_kernel(g->topo_dev, &a, ns, GMX_STK_LDS_BYTES(g->topo.lds_misc),
-                                   a.mask != nullptr, g->stock_staged, g->stream));
+                                   a.mask != nullptr, g->stock_staged, topo_tables_pow2(g->topo), g->stream));
   else
     HIPCHK(gmx_launch_bank_kernel(g->topo_dev, &a, ns, g->lds_bytes, a.mask != nullptr, g->topo.l0,
                                   g->topo.l1, g->topo.n_skip, g->topo.has_final,

@@ -15,7 +15,7 @@ def beq(a, b):
                           np.ascontiguousarray(b, np.float32).view(np.uint32))
 
 
-def run(gpu, topo, streams, chunk, force_general, mask=True, learn=True, exact=False, pairs=False, staged=-1):
+def run(gpu, topo, streams, chunk, force_general, mask=True, learn=True, exact=False, pairs=False, staged=-1, outputs=True):
     S, T = len(streams), len(streams[0][3])
     g = gpu.MixerGroup(topo, S)
     g.L.gmx_debug_stock_staged.argtypes = [C.c_void_p, C.c_int]
@@ -26,7 +26,7 @@ def run(gpu, topo, streams, chunk, force_general, mask=True, learn=True, exact=F
     g.L.gmx_debug_force_general(g.h, 1 if force_general else 0)
     g.L.gmx_debug_stock_exact.argtypes = [C.c_void_p, C.c_int]
     assert g.L.gmx_debug_stock_exact(g.h, 1 if exact else 0) == 0
-    b = gpu.Batch(g, chunk, outputs=True, mask=mask)
+    b = gpu.Batch(g, chunk, outputs=outputs, mask=mask)
     P = np.zeros((S, T), np.float32)
     O = np.zeros((S, T, topo.n_mixers), np.float32)
     for t0 in range(0, T, chunk):
@@ -38,7 +38,8 @@ def run(gpu, topo, streams, chunk, force_general, mask=True, learn=True, exact=F
         b.download(n)
         b.wait()
         P[:, t0:t0 + n] = b.p[:, :n]
-        O[:, t0:t0 + n] = b.outputs[:, :n]
+        if outputs:
+            O[:, t0:t0 + n] = b.outputs[:, :n]
     return g, P, O
 
 
@@ -68,6 +69,14 @@ def test_stock_kernel_equals_general_kernel_and_oracle(gpu, oracle, kw, mask):
     assert beq(P1, P3) and beq(O1, O3)
     for s in range(S):
         assert g1.export(s) == g3.export(s)
+    # Predict + Learn with only the probabilities stored: the kernel's "plain" build (mode tests folded at
+    # compile time), rows through the LDS images and lane-private
+    for staged in (1, 0):
+        g5, P5, _ = run(gpu, topo, streams, 700, force_general=False, mask=mask, staged=staged, outputs=False)
+        assert beq(P1, P5), staged
+        for s in range(S):
+            assert g1.export(s) == g5.export(s), (staged, s)
+        g5.close()
     # the lane-pair kernel (gmx_wide.hip instantiated for 90 inputs) gives the same floats
     g4, P4, O4 = run(gpu, topo, streams, 700, force_general=False, mask=mask, pairs=True)
     assert beq(P1, P4) and beq(O1, O4)
@@ -104,6 +113,33 @@ def test_stock_kernel_non_finite_values_stay_where_the_reference_puts_them(gpu, 
     assert np.array_equal(np.isfinite(out), fin) and not fin.all()
     assert beq(out[fin], o_ref[200][fin])
     g.close()
+
+
+def test_stock_kernel_plain_build_redoes_a_bit_with_non_finite_values(gpu, oracle):
+    """The same through the batched Predict + Learn launch that stores probabilities only (the "plain" build):
+    an infinite active input in the middle of a run, with and without active masks; the probabilities equal the
+    general kernel's, the banks afterwards those of the build with the mode tests."""
+    topo = topology.stock(90)
+    T = 300
+    for mask in (True, False):
+        pred, act, ctx, bits = oracle.synth(90, 33, T, seed=911, ctx_mode=3, ctx_mod=4, bit_mode=1)
+        pred, act, ctx = pred.copy(), act.copy(), ctx.copy()
+        pred[150, 7] = np.inf
+        act[150, 7] = 1
+        ctx[150:, 3] = 0x12345      # mixer 3 on a row it has never seen while the others blow up
+        st = [(pred, act, ctx, bits)]
+        ga, Pa, _ = run(gpu, topo, st, 100, force_general=True, mask=mask)
+        for staged in (1, 0):
+            gs, Ps, _ = run(gpu, topo, st, 100, force_general=False, mask=mask, staged=staged)
+            gb, Pb, _ = run(gpu, topo, st, 100, force_general=False, mask=mask, staged=staged, outputs=False)
+            assert np.array_equal(Pa.view(np.uint32), Pb.view(np.uint32)), (mask, staged)
+            assert np.array_equal(Ps.view(np.uint32), Pb.view(np.uint32)), (mask, staged)
+            # the same instruction streams with and without the mode tests: the same bytes, NaN payloads included
+            # (against the general kernel the NaNs a learn step leaves in the weights differ in payload only)
+            assert gs.export(0) == gb.export(0), (mask, staged)
+            gs.close()
+            gb.close()
+        ga.close()
 
 
 def test_stock_kernel_forward_only_and_per_bit(gpu, oracle):
