@@ -826,7 +826,8 @@ static int batch_alloc(gmx_batch** out, gmx_group* g, int S, uint64_t max_bits, 
   } while (0)
   BCHK(hipMalloc((void**)&b->d_pred, R * t.n_pad * sizeof(float)));
   if (flags & GMX_BATCH_MASK) BCHK(hipMalloc((void**)&b->d_mask, R * t.mask_words * sizeof(uint32_t)));
-  BCHK(hipMalloc((void**)&b->d_ctx, R * t.m * sizeof(uint32_t)));
+  // (+ one record: gmx_stock_kernel's plain build reads, and ignores, the context word behind its last bit)
+  BCHK(hipMalloc((void**)&b->d_ctx, (R + 1) * t.m * sizeof(uint32_t)));
   BCHK(hipMalloc((void**)&b->d_bits, R));
   BCHK(hipMalloc((void**)&b->d_p, R * sizeof(float)));
   if (flags & GMX_BATCH_OUTPUTS) BCHK(hipMalloc((void**)&b->d_out, R * t.m * sizeof(float)));
