@@ -174,6 +174,18 @@ __device__ __forceinline__ float gmx_wave_logistic_and_age(float p, const uint64
   return gmx_logistic_tab(p, tab);
 }
 
+// The same when the caller already knows whether every lane that matters has |p| < 64 (gmx_stock_kernel's plain
+// build learns it from the test it makes for non-finite outputs anyway; lanes that do not matter may hold anything).
+__device__ __forceinline__ float gmx_wave_logistic_and_age_hint(float p, const uint64_t* tab, uint64_t rs, uint64_t ms,
+                                                             bool p_small, double& age) {
+  if (p_small && __ballot((uint32_t)((rs | ms) >> 32) != 0u) == 0) {
+    age = gmx_row_age_short(rs, ms);
+    return gmx_logistic_short(p, tab);
+  }
+  age = (double)rs / (double)ms;
+  return gmx_logistic_tab(p, tab);
+}
+
 // Either alone (the per-bit kernels learn in a later command than they predict).
 __device__ __forceinline__ float gmx_wave_logistic(float p, const uint64_t* tab) {
   double unused;
