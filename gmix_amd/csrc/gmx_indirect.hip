@@ -97,17 +97,27 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
   uint8_t* const rmn = nsn + 512;
   uint32_t* const mw = (uint32_t*)(rmn + 512) + 8 * half;
   float* const gp = (float*)(bank + dv->pred_off);
-  for (int i = threadIdx.x; i < K * 512; i += 128) ptab[i] = gp[i];
+  uint32_t big = 0;  // any logit of the stream at or beyond 32 in magnitude (or not a number)?
+  for (int i = threadIdx.x; i < K * 512; i += 128) {
+    const float v = gp[i];
+    ptab[i] = v;
+    big |= (gmx_f2u(v) & 0x7fffffffu) >= 0x42000000u ? 1u : 0u;
+  }
   if (threadIdx.x < 32) s_tab[threadIdx.x] = gmx_exp2f_tab[threadIdx.x];
   for (int i = threadIdx.x; i < 512; i += 128) {
     nsn[i] = dv->ns_next[i];
     rmn[i] = dv->rm_next[i];
   }
-  __syncthreads();
+  // Logits that start below 32 in magnitude stay there while learning rates are at most 1: a step adds
+  // (bit - logistic(p)) * lr, at most lr below 17 and nothing at all beyond it (1 - logistic(17) is under half an ulp of
+  // 17 already).  Then every logistic of the launch may take the short way of gmx_math.h (no special cases of expf,
+  // no scaling steps in the division) without asking again bit by bit: `small` is block-uniform.
+  const int any_big = __syncthreads_or((int)big);
 
   const bool on = lane < K;
   const int ml = on ? lane : 0;
   const GmxIndModelDev d = dv->m[ml];
+  const bool small = !any_big && __ballot(!(__builtin_fabsf(d.lr) <= 1.0f)) == 0;
   uint8_t* const tab = bank + d.tab_off + half;  // this half's byte of entry i: tab[2 * i]
   float* const slots = (float*)(bank + dv->slots_off);
   float val = slots[2 * ml + half];
@@ -267,8 +277,9 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
     // register when bit j+1 reads the same state (every other lane-bit on the bench's records): the LDS round
     // trip leaves the chain of dependent operations, which is what this loop waits for.
     float q_fwd = 0.f, p0_fwd = 0.f;  // the logits of the next bit of a shaped block: lp[e[j+1]] and lp[0]
-    auto do_bit = [&](Block& cur, int j, uint32_t bit, uint32_t& e_new, auto shaped_tag) {
+    auto do_bit = [&](Block& cur, int j, uint32_t bit, uint32_t& e_new, auto shaped_tag, auto small_tag) {
       constexpr bool kShaped = decltype(shaped_tag)::value;
+      constexpr bool kSmall = decltype(small_tag)::value;
       // ---- Indirect::Predict (indirect.cpp:28-46) ------------------------------------------
       const uint32_t st = cur.e[j];
       const bool first = !kShaped || !LEARN || j == 0;
@@ -311,7 +322,7 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
           sn = seen ? st : 0u;
           p = seen ? q : p0;
         }
-        const float n = p + ((float)bit - gmx_logistic_tab(p, s_tab)) * d.lr;
+        const float n = p + ((float)bit - (kSmall ? gmx_logistic_short(p, s_tab) : gmx_logistic_tab(p, s_tab))) * d.lr;
         e_new = nextp[2 * sn + bit];
         lp[sn] = n;
         tab[2ull * cur.idx[j]] = (uint8_t)e_new;
@@ -351,12 +362,15 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
       block_indices(nxt, rn);
       IND_STAMP(1);
       uint32_t e_new[D];
-      if (cur.shaped) {  // one branch per block, not one per bit
+      if (cur.shaped && small) {  // one branch per block, not one per bit
 #pragma unroll
-        for (int j = 0; j < D; ++j) do_bit(cur, j, bit_c[j], e_new[j], std::true_type{});
+        for (int j = 0; j < D; ++j) do_bit(cur, j, bit_c[j], e_new[j], std::true_type{}, std::true_type{});
+      } else if (cur.shaped) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) do_bit(cur, j, bit_c[j], e_new[j], std::true_type{}, std::false_type{});
       } else {
 #pragma unroll
-        for (int j = 0; j < D; ++j) do_bit(cur, j, bit_c[j], e_new[j], std::false_type{});
+        for (int j = 0; j < D; ++j) do_bit(cur, j, bit_c[j], e_new[j], std::false_type{}, std::false_type{});
       }
       IND_STAMP(2);
       if (t0 + D < T) {
@@ -390,7 +404,7 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
       cur.shaped = false;  // its records past T are clamped copies: entries repeat
 #pragma unroll
       for (int j = 0; j < D; ++j)
-        if (t0 + j < T) do_bit(cur, j, bit_c[j], e_new, std::false_type{});
+        if (t0 + j < T) do_bit(cur, j, bit_c[j], e_new, std::false_type{}, std::false_type{});
     }
 #ifdef GMX_IND_PROF
     if (prof_on)

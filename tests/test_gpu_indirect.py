@@ -311,6 +311,32 @@ def test_indirect_device_synth_is_the_oracles_stream(gpu, oracle):
     g.close()
 
 
+@pytest.mark.parametrize("lrs", [(0.02, 1.0, 0.005), (0.02, 1.5, 0.005), (3.0, 0.02, 0.7)])
+def test_indirect_logistic_short_and_general_way(gpu, oracle, lrs):
+    """The batched kernel takes the logistic's short instruction sequence for a whole launch when every logit of
+    the stream starts below 32 in magnitude and no learning rate exceeds 1 (then none can ever reach 64, where the
+    short way ends), and the general function otherwise: learning rates at 1, and beyond (logits then move in steps
+    larger than 1 and the general function runs), byte-shaped records, long enough for logits to saturate."""
+    _, z = goldenlib.load("ind_tiny_dense")
+    models = [(256, lrs[0]), (65536, lrs[1]), (32768, lrs[2])]
+    S, T = 2, 6000
+    g = gpu.IndirectGroup(models, z["ns_next"], z["rm_next"], S)
+    b = gpu.IndirectBatch(g, T)
+    b.fill_synthetic(T, seed=4321, restart=True, ctx_mod=(20, 0, 300, 7))   # few contexts: states are revisited
+    g.run(b, T, learn=True)
+    b.download(T)
+    b.wait()
+    for s in range(S):
+        ctx, bc, bits = oracle.ind_synth(len(models), T, seed=(4321 + s * 0x9E3779B97F4A7C15) % (1 << 64),
+                                         ctx_mod=(20, 0, 300, 7))
+        ob = oracle.IndirectBank(models, z["ns_next"], z["rm_next"])
+        p, a = ob.run(ctx, bc, bits)
+        assert np.array_equal(u32(b.predictions[s, :T]), u32(p)) and np.array_equal(b.active[s, :T], a)
+        assert g.export(s) == ob.export()
+    b.close()
+    g.close()
+
+
 @pytest.mark.parametrize("shape", ["random", "shifted_bytes", "near_contexts", "repeated_bytes"])
 def test_indirect_block_pipeline_on_irregular_records(gpu, oracle, shape):
     """The batched kernel fetches a block's table entries one block ahead and patches what the block in
