@@ -56,6 +56,7 @@ def lib():
     L.gmx_last_error.restype = C.c_char_p
     L.gmx_build_info.restype = C.c_char_p
     L.gmx_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.gmx_device_pci_bus_id.argtypes = [i32, C.c_char_p, C.c_size_t]
     L.gmx_group_create.argtypes = [C.POINTER(vp), C.POINTER(TopologyStruct), i32, i32]
     L.gmx_group_destroy.argtypes = [vp]
     L.gmx_group_destroy.restype = None
@@ -85,6 +86,7 @@ def lib():
     L.gmx_batch_wait.argtypes = [vp]
     L.gmx_batch_fill_synthetic.argtypes = [vp, u64, u64, u64, i32, u32, u32, i32]
     L.gmx_group_run.argtypes = [vp, vp, u64, i32, C.POINTER(C.c_float)]
+    L.gmx_group_run_ragged.argtypes = [vp, vp, C.POINTER(u64), i32]
     L.gmx_bank_export.argtypes = [vp, i32, vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t)]
     L.gmx_bank_import.argtypes = [vp, i32, vp, C.c_size_t, vp, C.c_size_t]
     L.gmx_bank_copy.argtypes = [vp, i32, vp, i32]
@@ -170,13 +172,13 @@ def check(status, where):
 
 # Every symbol include/gmxmix.h declares; tests assert the built library exports them all.
 ABI_SYMBOLS = [
-    "gmx_strerror", "gmx_last_error", "gmx_device_count", "gmx_build_info", "gmx_group_create",
+    "gmx_strerror", "gmx_last_error", "gmx_device_count", "gmx_device_pci_bus_id", "gmx_build_info", "gmx_group_create",
     "gmx_group_destroy", "gmx_group_n_streams", "gmx_group_n_mixers", "gmx_group_n_inputs",
     "gmx_group_bank_bytes", "gmx_group_reset", "gmx_group_sync", "gmx_group_timer_start", "gmx_group_timer_stop", "gmx_bank_forward", "gmx_bank_learn",
     "gmx_batch_create", "gmx_batch_destroy", "gmx_batch_n_pad", "gmx_batch_mask_words",
     "gmx_batch_max_bits", "gmx_batch_predictions", "gmx_batch_active_mask", "gmx_batch_contexts",
     "gmx_batch_bits", "gmx_batch_p", "gmx_batch_outputs", "gmx_batch_upload", "gmx_batch_download",
-    "gmx_batch_wait", "gmx_batch_fill_synthetic", "gmx_group_run", "gmx_bank_export",
+    "gmx_batch_wait", "gmx_batch_fill_synthetic", "gmx_group_run", "gmx_group_run_ragged", "gmx_bank_export",
     "gmx_bank_import", "gmx_bank_copy", "gmx_bank_memory_usage",
     "gmx_lockstep_create", "gmx_lockstep_destroy", "gmx_lockstep_batch", "gmx_lockstep_is_persistent", "gmx_lockstep_predict", "gmx_lockstep_learn", "gmx_lockstep_learn_predict",
     "gmx_indirect_create", "gmx_indirect_destroy", "gmx_indirect_n_streams", "gmx_indirect_n_models",

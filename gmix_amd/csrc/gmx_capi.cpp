@@ -293,6 +293,19 @@ extern "C" int gmx_device_count(int* count) {
   return GMX_OK;
 }
 
+// "0000:c1:00.0": the key of /sys/bus/pci/devices/<id>/numa_node (host threads that feed a device belong on its node)
+extern "C" int gmx_device_pci_bus_id(int device, char* buf, size_t len) {
+  if (!buf || len < 13) return GMX_ERR_INVALID;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return GMX_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) return GMX_ERR_INVALID;
+  HIPCHK(hipDeviceGetPCIBusId(buf, (int)len, device));
+  return GMX_OK;
+}
+
 static uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 static uint64_t round_up64(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
@@ -1004,6 +1017,26 @@ extern "C" int gmx_group_run(gmx_group* g, gmx_batch* b, uint64_t n_bits, int le
   std::fill(g->fwd_done.begin(), g->fwd_done.end(), 0);
   return launch_run(g, b, 0, 0, g->S, n_bits, GMX_MODE_PREDICT | (learn ? GMX_MODE_LEARN : 0u),
                     kernel_ms);
+}
+
+// Streams of different lengths in one call (many files compressed side by side end at different bits):
+// maximal runs of neighbouring streams with the same count share a launch, a stream with 0 bits sits out.
+extern "C" int gmx_group_run_ragged(gmx_group* g, gmx_batch* b, const uint64_t* n_bits, int learn) {
+  if (!g || !b || b->g != g || b->S != g->S || !n_bits) return GMX_ERR_INVALID;
+  for (int s = 0; s < g->S; ++s)
+    if (n_bits[s] > b->max_bits) return GMX_ERR_INVALID;
+  HIPCHK(hipSetDevice(g->device));
+  int rc = sessions_close(g, false);
+  if (rc) return rc;
+  std::fill(g->fwd_done.begin(), g->fwd_done.end(), 0);
+  for (int s0 = 0; s0 < g->S;) {
+    int s1 = s0 + 1;
+    while (s1 < g->S && n_bits[s1] == n_bits[s0]) ++s1;
+    rc = launch_run(g, b, s0, s0, s1 - s0, n_bits[s0], GMX_MODE_PREDICT | (learn ? GMX_MODE_LEARN : 0u), nullptr);
+    if (rc) return rc;
+    s0 = s1;
+  }
+  return GMX_OK;
 }
 
 // ---- per-bit surface -------------------------------------------------------------------

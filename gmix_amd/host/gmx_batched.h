@@ -1,0 +1,369 @@
+// gmx_batched.h -- the run-ahead compressor: runner_utils::Compress (src/runner/runner-utils.cpp:43-67) with the
+// 33 mixers of the Predictor batched on an MI355X.
+//
+// The reference codes one bit at a time: Predict -> Encode -> Perceive -> Learn, all 121 models in turn.  But in
+// compression every bit is known beforehand, and no feature model ever reads a mixer output
+// (predictor.cpp:360-387), so the loop splits:
+//
+//     host, bits t .. t+T      Predictor::Predict / Perceive / Learn as in the reference -- the 88 feature models
+//                              run, the mixers (gmx::GpuMixer in run-ahead mode, gmx_model_adapter.h) only record
+//                              {predictions, active_models, 33 contexts, bit} into the pinned arrays of a gmx_batch
+//     device, bits t-T .. t    gmx_batch_upload / gmx_group_run / gmx_batch_download on the chunk recorded before
+//                              (two batches used alternately: BASELINE configs[3]'s double-buffered batches)
+//     host, bits t-2T .. t-T   Encoder::Encode (coder/encoder.cpp:10-25) drains the probabilities that came back
+//
+// Same Predictor, same feature models, same coder, same bytes as `gmix -c` -- tests/test_gpu_batched.py compares
+// them with the stock build's.  Compiled against the reference like gmx_model_adapter.h (-I<gmix>/src); the switch
+// in the reference is one call in RunCompression (runner-utils.cpp:118):
+//     -  Compress(*input_bytes, &data_in, &data_out, output_bytes, &p);
+//     +  gmx::BatchedCompress(*input_bytes, &data_in, &data_out, output_bytes, &p);
+// oracle/ref_build/Makefile builds the reference's CLI that way (gmix_batched).
+//
+// Decompression cannot run ahead (the decoder learns each bit from Predict's own result, decoder.cpp:19-39): it
+// keeps the per-bit path of gmx_model_adapter.h.
+//
+// Analysis (runner-utils.cpp:47 switches it on for every compression): the Predictor keeps its per-bit
+// entropy averages of the feature models; the averages of the mixers it analyses (the final mixer,
+// predictor.cpp:354-357) need outputs that are a chunk away, so this file computes them as
+// Predictor::UpdateEntropy does (predictor.cpp:439-469) when the chunk returns, and writes the rows of
+// analysis/entropy.tsv / memory.tsv (predictor.cpp:471-504) itself, each from the values captured at its
+// sample bit.  The tables come out identical to the stock build's.
+//
+// Many files: BatchedCompressFiles runs one Predictor per file on a thread of its own, all mixers in ONE gmx_group
+// (gmx::MixerPool), one launch per chunk for all files.
+#ifndef GMX_BATCHED_H_
+#define GMX_BATCHED_H_
+
+#include <sched.h>
+
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <deque>
+#include <filesystem>
+#include <iomanip>
+#include <thread>
+
+#include "coder/encoder.h"          // the reference's
+#include "gmx_model_adapter.h"
+#include "predictor.h"              // the reference's
+#include "runner/runner-utils.h"    // the reference's (WriteHeader)
+
+namespace gmx {
+
+struct BatchedOptions {
+  uint64_t chunk_bits = 2048;  // bits per stream and launch (a multiple of 8: chunks end on byte boundaries)
+  bool analysis = true;        // runner-utils.cpp:47
+  bool progress = true;        // runner-utils.cpp:59-63
+  bool pin_threads = true;     // BatchedCompressFiles: threads onto the cores of the device's NUMA node
+};
+
+// The cores of the NUMA node the device hangs on (sysfs), or nothing when that cannot be told.
+inline std::vector<int> DeviceNodeCpus(int device) {
+  std::vector<int> cpus;
+  char bus[64] = {0};
+  if (gmx_device_pci_bus_id(device, bus, sizeof bus) != GMX_OK) return cpus;
+  std::string id(bus);
+  for (auto& ch : id) ch = (char)tolower(ch);
+  std::ifstream nf("/sys/bus/pci/devices/" + id + "/numa_node");
+  int node = -1;
+  if (!(nf >> node) || node < 0) return cpus;
+  std::ifstream lf("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+  std::string list;
+  if (!std::getline(lf, list)) return cpus;
+  size_t pos = 0;
+  while (pos < list.size()) {  // "0-15,128-143"
+    size_t end = list.find(',', pos);
+    if (end == std::string::npos) end = list.size();
+    const std::string part = list.substr(pos, end - pos);
+    const size_t dash = part.find('-');
+    const int a = atoi(part.c_str());
+    const int b = dash == std::string::npos ? a : atoi(part.c_str() + dash + 1);
+    for (int c = a; c <= b; ++c) cpus.push_back(c);
+    pos = end + 1;
+  }
+  return cpus;
+}
+
+// Keeps the calling thread on those cores that it is allowed on anyway (a container's share); no-op otherwise.
+inline bool PinThreadToDeviceNode(int device) {
+  const std::vector<int> cpus = DeviceNodeCpus(device);
+  if (cpus.empty()) return false;
+  cpu_set_t now, want;
+  CPU_ZERO(&now);
+  CPU_ZERO(&want);
+  if (sched_getaffinity(0, sizeof now, &now) != 0) return false;
+  int n = 0;
+  for (int c : cpus)
+    if (c < CPU_SETSIZE && CPU_ISSET(c, &now)) {
+      CPU_SET(c, &want);
+      ++n;
+    }
+  return n > 0 && sched_setaffinity(0, sizeof want, &want) == 0;
+}
+
+// One stream's compression: the loop of runner_utils::Compress, the coder behind the device.
+class BatchedCompressor : public RunAheadSink {
+ public:
+  BatchedCompressor(Predictor* p, std::ofstream* os, const BatchedOptions& opt)
+      : p_(p), enc_(os), opt_(opt), bank_(GpuMixerBank::Of(p, sizeof(Predictor))) {}
+
+  // 0, or a gmx_status (nothing is coded on the CPU instead: a Predictor whose mixers are not gmx::GpuMixer is
+  // refused).  *output_bytes as runner_utils::Compress leaves it.
+  int Run(unsigned long long input_bytes, std::ifstream* is, std::ofstream* os, unsigned long long* output_bytes) {
+    if (!bank_) {
+      fprintf(stderr, "gmx::BatchedCompress: this Predictor's mixers are not gmx::GpuMixer\n");
+      return GMX_ERR_INVALID;
+    }
+    ShortTermMemory& stm = bank_->stm();
+    const int sample_frequency = (int)(8 * input_bytes / 1000);  // runner-utils.cpp:47 (the call narrows to int)
+    if (opt_.analysis) {
+      p_->EnableAnalysis(sample_frequency);
+      F_ = sample_frequency > 0 ? sample_frequency : 0;
+    }
+    if (F_ > 0) {
+      // the Predictor keeps averaging per bit but leaves the rows to this object (they need the device's outputs)
+      p_->SetAnalysisFrequency(kNever);
+      const int N = stm.num_predictions;
+      for (int i = 0; i < (int)stm.model_enable_analysis.size(); ++i) {
+        if (!stm.model_enable_analysis[i]) continue;
+        analysed_.push_back(i);
+        if (i >= N) {
+          on_device_.push_back((int)analysed_.size() - 1);
+          ema_.push_back(stm.entropy[i]);
+        }
+      }
+    }
+    uint64_t chunk = opt_.chunk_bits < 8 ? 8 : opt_.chunk_bits & ~7ull;
+    int rc = bank_->BeginRunAhead(this, chunk);
+    if (rc) return rc;
+    const unsigned long long percent = 1 + (input_bytes / 10000);
+    if (opt_.progress) {
+      fprintf(stderr, "\r                     \r");
+      fflush(stderr);
+    }
+    for (unsigned long long pos = 0; pos < input_bytes && bank_->status() == 0; ++pos) {
+      const char c = is->get();
+      for (int j = 7; j >= 0; --j) {
+        const int bit = (c >> j) & 1;
+        p_->Predict();   // the feature models predict; the mixers record their inputs
+        if (F_ > 0 && stm.bits_seen > 0 && stm.bits_seen % (unsigned long long)kNever == 0) {
+          p_->SetAnalysisFrequency(kNever - 1);  // (never a row of the Predictor's own)
+          p_->Perceive(bit);
+          p_->SetAnalysisFrequency(kNever);
+        } else {
+          p_->Perceive(bit);
+        }
+        if (F_ > 0 && stm.bits_seen % (unsigned long long)F_ == 0 && stm.bits_seen > 0) Capture();
+        ++recorded_;
+        p_->Learn();     // the feature models learn; the mixers record the bit (a full chunk goes to the device)
+      }
+      if (opt_.progress && pos % percent == 0) {
+        fprintf(stderr, "\rprogress: %.2f%%", 100.0 * pos / input_bytes);
+        fflush(stderr);
+      }
+    }
+    rc = bank_->EndRunAhead();
+    if (rc == GMX_OK) rc = bank_->status();
+    if (F_ > 0) {
+      for (size_t k = 0; k < on_device_.size(); ++k) stm.entropy[analysed_[on_device_[k]]] = ema_[k];
+      p_->SetAnalysisFrequency(sample_frequency);
+    }
+    if (rc) return rc;
+    enc_.Flush();
+    *output_bytes = os->tellp();
+    return GMX_OK;
+  }
+
+  // RunAheadSink: a chunk is back
+  void Drain(const float* p, const uint8_t* bits, const float* outputs, int n_mixers, uint64_t n) override {
+    const int N = bank_->stm().num_predictions;
+    for (uint64_t i = 0; i < n; ++i) {
+      enc_.Encode(bits[i], p[i]);
+      if (F_ > 0) {
+        for (size_t k = 0; k < on_device_.size(); ++k)  // Predictor::UpdateEntropy (predictor.cpp:439-469)
+          ema_[k] = Average(ema_[k], outputs[i * n_mixers + (analysed_[on_device_[k]] - N)], bits[i]);
+        if (!rows_.empty() && rows_.front().bit == drained_) {
+          WriteRow(rows_.front());
+          rows_.pop_front();
+        }
+      }
+      ++drained_;
+    }
+  }
+
+ private:
+  static constexpr int kNever = INT_MAX;
+  struct Row {
+    uint64_t bit;  // position in this run
+    unsigned long long bits_seen;
+    std::vector<double> entropy;
+    std::vector<unsigned long long> memory;
+    size_t history;
+  };
+  static double Average(double e, float x, int bit) {
+    float prob = Sigmoid::Logistic(x);
+    float eps = 0.01;
+    if (prob < eps)
+      prob = eps;
+    else if (prob > 1 - eps)
+      prob = 1 - eps;
+    float entropy;
+    if (bit)
+      entropy = std::log2(prob);
+    else
+      entropy = std::log2(1 - prob);
+    double alpha = 0.00001;
+    return (1 - alpha) * e + alpha * entropy;
+  }
+  // What Predictor::RunAnalysis (predictor.cpp:471-504) reads at a sample bit, taken at that bit.
+  void Capture() {
+    ShortTermMemory& stm = bank_->stm();
+    LongTermMemory& ltm = bank_->ltm();
+    Row r;
+    r.bit = recorded_;
+    r.bits_seen = stm.bits_seen;
+    for (int i : analysed_) {
+      r.entropy.push_back(stm.entropy[i]);
+      if (i < stm.num_predictions)
+        r.memory.push_back(stm.prediction_index_to_model_ptr[i]->GetMemoryUsage(stm, ltm));
+      else
+        r.memory.push_back(stm.mixer_index_to_model_ptr[i - stm.num_predictions]->GetMemoryUsage(stm, ltm));
+    }
+    r.history = ltm.history.size();
+    rows_.push_back(std::move(r));
+  }
+  void WriteRow(Row& r) {
+    for (size_t k = 0; k < on_device_.size(); ++k) r.entropy[on_device_[k]] = ema_[k];
+    std::ofstream entropy_file("analysis/entropy.tsv", std::ios::app);
+    std::ofstream memory_file("analysis/memory.tsv", std::ios::app);
+    entropy_file << r.bits_seen;
+    memory_file << r.bits_seen;
+    for (size_t a = 0; a < analysed_.size(); ++a) {
+      entropy_file << std::fixed << std::setprecision(5) << "\t" << -r.entropy[a];
+      memory_file << "\t" << r.memory[a];
+    }
+    memory_file << "\t" << r.history;
+    entropy_file << std::endl;
+    memory_file << std::endl;
+  }
+
+  Predictor* p_;
+  Encoder enc_;
+  BatchedOptions opt_;
+  std::shared_ptr<GpuMixerBank> bank_;
+  int F_ = 0;
+  std::vector<int> analysed_;   // entropy indices with analysis on, ascending (the tables' columns)
+  std::vector<int> on_device_;  // positions in analysed_ that are mixers
+  std::vector<double> ema_;     // their averages, up to the last bit that came back
+  std::deque<Row> rows_;
+  uint64_t recorded_ = 0, drained_ = 0;
+};
+
+// runner_utils::Compress (runner-utils.cpp:43-67), argument for argument; returns 0 or a gmx_status.
+inline int BatchedCompress(unsigned long long input_bytes, std::ifstream* is, std::ofstream* os,
+                           unsigned long long* output_bytes, Predictor* p, const BatchedOptions& opt = BatchedOptions()) {
+  BatchedCompressor c(p, os, opt);
+  int rc = c.Run(input_bytes, is, os, output_bytes);
+  if (rc) fprintf(stderr, "\ngmx::BatchedCompress: %s\n", gmx_strerror(rc));
+  return rc;
+}
+
+// ---- many files, one device group ---------------------------------------------------------------------------
+struct BatchedJob {
+  std::string input_path, output_path;
+  unsigned long long input_bytes = 0, output_bytes = 0;
+  int status = 0;        // 0 or a gmx_status / -100 for a file that would not open
+  double seconds = 0;    // the compression loop alone (Predictor construction not included)
+};
+struct BatchedStats {
+  double wall_seconds = 0;     // first compression loop's start to the last one's end (all Predictors built before)
+  double build_seconds = 0;    // building the Predictors, one after the other (they draw from rand(), predictor.cpp:18)
+  uint64_t launches = 0;       // chunks of all streams queued on the device
+  uint64_t bits = 0;           // bits of all streams mixed there
+  int pinned_threads = 0;      // threads kept on the cores of the device's NUMA node
+};
+
+// runner_utils::RunCompression (runner-utils.cpp:88-121) for every job at once: a Predictor and a thread per
+// file, their mixers in one gmx_group of jobs.size() streams.  Returns the number of jobs that failed.
+inline int BatchedCompressFiles(std::vector<BatchedJob>& jobs, const BatchedOptions& opt_in = BatchedOptions(),
+                                BatchedStats* stats = nullptr) {
+  BatchedOptions opt = opt_in;
+  opt.analysis = false;  // (analysis/*.tsv are one pair of files per process: not with several Predictors at once)
+  opt.progress = false;
+  const int S = (int)jobs.size();
+  if (S == 0) return 0;
+  MixerPool pool(S);
+  pool.Install();
+  std::mutex construct;  // Predictor::Predictor draws the LSTM's weights from rand() after srand() (predictor.cpp:18)
+  std::mutex start_mu;
+  std::condition_variable start_cv;
+  int ready = 0;
+  std::atomic<int> pinned{0};
+  using clock = std::chrono::steady_clock;
+  const clock::time_point tb = clock::now();
+  clock::time_point t0 = tb;
+  std::vector<clock::time_point> ends(S, tb);
+  std::vector<std::thread> threads;
+  for (int s = 0; s < S; ++s) {
+    threads.emplace_back([&, s] {
+      BatchedJob& job = jobs[s];
+      if (opt.pin_threads && PinThreadToDeviceNode(pool.device())) ++pinned;
+      std::ifstream data_in(job.input_path, std::ios::in | std::ios::binary);
+      std::ofstream data_out;
+      std::unique_ptr<Predictor> p;
+      if (data_in.is_open()) {
+        data_in.seekg(0, std::ios::end);
+        job.input_bytes = data_in.tellg();
+        data_in.seekg(0, std::ios::beg);
+        data_out.open(job.output_path, std::ios::out | std::ios::binary);
+      }
+      if (!data_in.is_open() || !data_out.is_open()) {
+        job.status = -100;
+      } else {
+        runner_utils::WriteHeader(job.input_bytes, &data_out);
+        std::lock_guard<std::mutex> lk(construct);
+        p.reset(new Predictor());
+      }
+      {  // all Predictors stand before the first one runs: the timed region is compression only
+        std::unique_lock<std::mutex> lk(start_mu);
+        if (++ready == S) {
+          t0 = clock::now();
+          start_cv.notify_all();
+        } else {
+          start_cv.wait(lk, [&] { return ready == S; });
+        }
+      }
+      if (!p) return;
+      const clock::time_point a = clock::now();
+      {
+        BatchedCompressor c(p.get(), &data_out, opt);
+        job.status = c.Run(job.input_bytes, &data_in, &data_out, &job.output_bytes);
+      }
+      ends[s] = clock::now();
+      job.seconds = std::chrono::duration<double>(ends[s] - a).count();
+      data_out.close();
+      std::lock_guard<std::mutex> lk(construct);  // (a Predictor gives back gigabytes: one at a time)
+      p.reset();
+    });
+  }
+  for (auto& t : threads) t.join();
+  pool.Uninstall();
+  int failed = 0;
+  for (auto& j : jobs) failed += j.status != 0;
+  if (pool.status() != 0) fprintf(stderr, "gmx::BatchedCompressFiles: %s\n", pool.error().c_str());
+  if (stats) {
+    clock::time_point t1 = t0;
+    for (auto& e : ends) t1 = std::max(t1, e);
+    stats->wall_seconds = std::chrono::duration<double>(t1 - t0).count();
+    stats->build_seconds = std::chrono::duration<double>(t0 - tb).count();
+    stats->launches = pool.rounds();
+    stats->bits = pool.bits_submitted();
+    stats->pinned_threads = pinned.load();
+  }
+  return failed;
+}
+
+}  // namespace gmx
+
+#endif  // GMX_BATCHED_H_

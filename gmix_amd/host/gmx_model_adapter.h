@@ -42,7 +42,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <memory>
 #include <string>
@@ -70,6 +73,13 @@ struct ChainProducer {
   // the results go where 41 x Indirect::Predict would have left them; nothing is pending afterwards
   virtual void Deliver(ShortTermMemory& stm, const float* pred, const uint8_t* active) = 0;
 };
+// Process-wide tables of the adapters.  The reference lets several Predictors live in one process
+// (runner-utils.cpp:291-292); here they may also be built and run on different threads (one file per thread,
+// MixerPool below), so every access goes through AdapterMutex().
+inline std::recursive_mutex& AdapterMutex() {
+  static std::recursive_mutex m;
+  return m;
+}
 inline std::map<const LongTermMemory*, ChainProducer*>& ChainProducers() {
   static std::map<const LongTermMemory*, ChainProducer*> r;
   return r;
@@ -86,11 +96,238 @@ inline bool ChainFused() {
   return on;
 }
 
-// All mixers of one Predictor: one gmx_group with one stream.
+// ------------------------------------------------------------------------------------------------
+// Run-ahead.  In compression and training the coded bits are known in advance and no feature model ever reads a
+// mixer output (predictor.cpp:360-387 only hands them to later mixers, the final squash and the analysis), so
+// the 88 feature models of a Predictor can run T bits ahead while the device mixes the T bits before: the
+// mixers' Predict then only RECORDS its inputs {predictions, active_models, 33 contexts} and Learn the coded
+// bit, straight into the pinned arrays of a gmx_batch; a full chunk is uploaded and run behind the chunk
+// before it (two batches used alternately) and its probabilities come back one
+// chunk later, in order, to whoever consumes them (the arithmetic coder: gmx_batched.h).
+// ------------------------------------------------------------------------------------------------
+struct RunAheadSink {
+  virtual ~RunAheadSink() {}
+  // n bits of this stream, oldest first: p[i] is what Predictor::Predict() would have returned for bit i,
+  // bits[i] the bit that was then perceived, outputs[i * n_mixers + j] mixer j's output (logit domain).
+  virtual void Drain(const float* p, const uint8_t* bits, const float* outputs, int n_mixers, uint64_t n) = 0;
+};
+
+// The mixer banks of up to n_streams Predictors in ONE gmx_group (one stream each), and the two-batch ring
+// their run-ahead chunks travel through.  A bank constructed while a pool is installed takes a stream of it;
+// otherwise every bank owns a pool of one stream, which is the plain drop-in.  The Predictors may live on
+// different threads (one file per thread): every C-ABI call on the shared group happens under the pool's
+// mutex, the chunk of a round is submitted by whichever stream arrives last, and a stream only ever touches
+// its own stretch of the batches' arrays.
+class MixerPool {
+ public:
+  explicit MixerPool(int n_streams, int device = -1) : S_(n_streams < 1 ? 1 : n_streams), device_(device), used_(S_, 0) {
+    if (device_ < 0) {
+      const char* dev = getenv("GMX_DEVICE");
+      device_ = dev ? atoi(dev) : 0;
+    }
+  }
+  ~MixerPool() {
+    Uninstall();
+    for (gmx_batch* b : ring_)
+      if (b) gmx_batch_destroy(b);
+    if (group_) gmx_group_destroy(group_);
+  }
+  MixerPool(const MixerPool&) = delete;
+  MixerPool& operator=(const MixerPool&) = delete;
+
+  static MixerPool*& Installed() {  // guarded by AdapterMutex()
+    static MixerPool* p = nullptr;
+    return p;
+  }
+  void Install() {
+    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
+    Installed() = this;
+    shared_ = true;
+  }
+  void Uninstall() {
+    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
+    if (Installed() == this) Installed() = nullptr;
+  }
+  int n_streams() const { return S_; }
+  int device() const { return device_; }
+  gmx_group* group() const { return group_; }
+  // 0, or the status of the first C-ABI call that failed on this pool (shared pools report instead of aborting)
+  int status() const { return status_.load(); }
+  std::string error() const {
+    std::lock_guard<std::mutex> lk(mu_);
+    return error_;
+  }
+  uint64_t chunk_bits() const { return T_; }
+  // bits of all streams submitted to the device so far, launches made
+  uint64_t bits_submitted() const { return bits_submitted_; }
+  uint64_t rounds() const { return round_; }
+
+ private:
+  friend class GpuMixerBank;
+  struct View {  // a stream's stretch of the batch whose results are back
+    const float* p = nullptr;
+    const float* out = nullptr;
+    const uint8_t* bits = nullptr;
+    uint64_t n = 0;
+  };
+  int Acquire() {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (int i = 0; i < S_; ++i)
+      if (!used_[i]) {
+        used_[i] = 1;
+        return i;
+      }
+    return -1;
+  }
+  void Release(int slot) {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (slot >= 0 && slot < S_) used_[slot] = 0;
+  }
+  int Fail(const char* what, int rc) {  // mu_ held
+    if (status_.load() == 0) {
+      error_ = std::string(what) + ": " + gmx_strerror(rc) + (rc == GMX_ERR_HIP ? std::string(" ") + gmx_last_error() : "");
+      status_.store(rc);
+    }
+    cv_.notify_all();
+    return rc;
+  }
+  // The group is made from the first bank's topology (all constructors of its Predictor have run by then);
+  // the other banks must describe the same one.  mu_ held.
+  int EnsureGroup(const gmx_topology& t) {
+    if (group_) {
+      bool same = t.n_inputs == n_inputs_ && (size_t)t.n_mixers == descs_.size() && (size_t)t.n_skip == skip_.size();
+      for (int j = 0; same && j < t.n_mixers; ++j)
+        same = t.mixers[j].layer == descs_[j].layer && t.mixers[j].table_size == descs_[j].table_size &&
+               t.mixers[j].learning_rate == descs_[j].learning_rate;
+      for (int i = 0; same && i < t.n_skip; ++i) same = t.skip_index[i] == skip_[i];
+      return same ? GMX_OK : GMX_ERR_INVALID;
+    }
+    n_inputs_ = t.n_inputs;
+    descs_.assign(t.mixers, t.mixers + t.n_mixers);
+    skip_.assign(t.skip_index, t.skip_index + t.n_skip);
+    return gmx_group_create(&group_, &t, S_, device_);
+  }
+  // ---- the ring ----
+  int Join(int slot, uint64_t chunk_bits) {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (status_.load()) return status_.load();
+    if (!ring_[0]) {
+      T_ = chunk_bits < 8 ? 8 : chunk_bits;
+      for (int k = 0; k < 2; ++k) {
+        int rc = gmx_batch_create(&ring_[k], group_, T_, GMX_BATCH_OUTPUTS | GMX_BATCH_MASK);
+        if (rc) return Fail("gmx_batch_create", rc);
+        if (!gmx_batch_predictions(ring_[k]) || !gmx_batch_active_mask(ring_[k]) || !gmx_batch_contexts(ring_[k]) ||
+            !gmx_batch_bits(ring_[k]) || !gmx_batch_p(ring_[k]) || !gmx_batch_outputs(ring_[k]))
+          return Fail("gmx_batch (pinned arrays)", GMX_ERR_NOMEM);
+      }
+      n_pad_ = gmx_batch_n_pad(ring_[0]);
+      mask_words_ = gmx_batch_mask_words(ring_[0]);
+      M_ = gmx_group_n_mixers(group_);
+      n_cur_.assign(S_, 0);
+      n_in_[0].assign(S_, 0);
+      n_in_[1].assign(S_, 0);
+    }
+    n_cur_[slot] = 0;
+    n_in_[0][slot] = n_in_[1][slot] = 0;
+    ++participants_;
+    return GMX_OK;
+  }
+  // where `slot` records the chunk it is filling
+  void Records(int slot, float** pred, uint32_t** mask, uint32_t** ctx, uint8_t** bits) {
+    std::lock_guard<std::mutex> lk(mu_);
+    gmx_batch* b = ring_[cur_];
+    *pred = gmx_batch_predictions(b) + (size_t)slot * T_ * n_pad_;
+    *mask = gmx_batch_active_mask(b) + (size_t)slot * T_ * mask_words_;
+    *ctx = gmx_batch_contexts(b) + (size_t)slot * T_ * M_;
+    *bits = gmx_batch_bits(b) + (size_t)slot * T_;
+  }
+  // Every stream has handed in its chunk: queue it behind the chunk before, wait for THAT one.  mu_ held.
+  void Lead() {
+    gmx_batch* b = ring_[cur_];
+    uint64_t maxn = 0, sum = 0;
+    for (int i = 0; i < S_; ++i) {
+      maxn = std::max(maxn, n_cur_[i]);
+      sum += n_cur_[i];
+    }
+    int rc = GMX_OK;
+    if (maxn > 0) {
+      if ((rc = gmx_batch_upload(b, maxn))) {
+        Fail("gmx_batch_upload", rc);
+      } else if ((rc = gmx_group_run_ragged(group_, b, n_cur_.data(), 1))) {
+        Fail("gmx_group_run_ragged", rc);
+      } else if ((rc = gmx_batch_download(b, maxn))) {
+        Fail("gmx_batch_download", rc);
+      } else {
+        busy_[cur_] = true;
+        bits_submitted_ += sum;
+      }
+    }
+    n_in_[cur_] = n_cur_;
+    std::fill(n_cur_.begin(), n_cur_.end(), 0);
+    const int other = cur_ ^ 1;
+    if (rc == GMX_OK && busy_[other]) {
+      busy_[other] = false;
+      if ((rc = gmx_batch_wait(ring_[other]))) Fail("gmx_batch_wait", rc);
+    }
+    cur_ = other;
+    arrived_ = 0;
+    ++round_;
+    cv_.notify_all();
+  }
+  // `slot` has recorded n bits into the chunk being filled.  Returns when that chunk is queued on the device
+  // and the chunk before it is back: *v is the stream's stretch of THAT one (the arrays it fills next).
+  int Arrive(int slot, uint64_t n, View* v) {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (status_.load()) return status_.load();
+    n_cur_[slot] = n;
+    const uint64_t my_round = round_;
+    if (++arrived_ >= participants_)
+      Lead();
+    else
+      cv_.wait(lk, [&] { return round_ != my_round || status_.load() != 0; });
+    if (status_.load()) return status_.load();
+    gmx_batch* b = ring_[cur_];
+    v->p = gmx_batch_p(b) + (size_t)slot * T_;
+    v->out = gmx_batch_outputs(b) + (size_t)slot * T_ * M_;
+    v->bits = gmx_batch_bits(b) + (size_t)slot * T_;
+    v->n = n_in_[cur_][slot];
+    n_in_[cur_][slot] = 0;
+    return GMX_OK;
+  }
+  void Leave(int slot) {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (participants_ > 0) --participants_;
+    if (!n_cur_.empty()) n_cur_[slot] = 0;
+    if (participants_ > 0 && arrived_ >= participants_ && status_.load() == 0) Lead();
+  }
+
+  const int S_;
+  int device_;
+  bool shared_ = false;
+  gmx_group* group_ = nullptr;
+  int n_inputs_ = 0;
+  std::vector<gmx_mixer_desc> descs_;
+  std::vector<int32_t> skip_;
+  std::vector<char> used_;
+  mutable std::mutex mu_;
+  std::condition_variable cv_;
+  std::atomic<int> status_{0};
+  std::string error_;
+  gmx_batch* ring_[2] = {nullptr, nullptr};
+  bool busy_[2] = {false, false};
+  int cur_ = 0;
+  uint64_t T_ = 0, round_ = 0, bits_submitted_ = 0;
+  int n_pad_ = 0, mask_words_ = 0, M_ = 0;
+  int participants_ = 0, arrived_ = 0;
+  std::vector<uint64_t> n_cur_, n_in_[2];
+};
+
+// All mixers of one Predictor: one stream of a gmx_group (its own, or a MixerPool's).
 class GpuMixerBank {
  public:
   // The bank of the Predictor that owns `ltm` (created on first use, gone with its last mixer).
   static std::shared_ptr<GpuMixerBank> For(ShortTermMemory& stm, LongTermMemory& ltm) {
+    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
     auto& reg = Registry();
     auto it = reg.find(&ltm);
     if (it != reg.end())
@@ -99,8 +336,24 @@ class GpuMixerBank {
     reg[&ltm] = sp;
     return sp;
   }
+  // The bank of the Predictor object at [p, p + size): its LongTermMemory is a member of it (predictor.h:41).
+  static std::shared_ptr<GpuMixerBank> Of(const void* p, size_t size) {
+    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
+    const char* lo = static_cast<const char*>(p);
+    for (auto& kv : Registry()) {
+      const char* k = reinterpret_cast<const char*>(kv.first);
+      if (k >= lo && k < lo + size)
+        if (auto sp = kv.second.lock()) return sp;
+    }
+    return nullptr;
+  }
   ~GpuMixerBank() {
-    if (group_) gmx_group_destroy(group_);
+    if (ra_) {
+      pool_->Leave(slot_);
+      ra_ = false;
+    }
+    pool_->Release(slot_);
+    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
     Registry().erase(&ltm_);
     ChainConsumers().erase(&ltm_);
   }
@@ -108,23 +361,118 @@ class GpuMixerBank {
   GpuMixerBank& operator=(const GpuMixerBank&) = delete;
 
   gmx_group* group() { return group_; }
+  int stream() const { return slot_; }
+  MixerPool* pool() { return pool_; }
+  ShortTermMemory& stm() { return stm_; }
+  LongTermMemory& ltm() { return ltm_; }
+  int n_mixers() const { return (int)descs_.size(); }
+  bool running_ahead() const { return ra_; }
+  // 0, or the status of the C-ABI call that failed (a bank of a shared pool reports; a bank of its own aborts,
+  // the convention of the reference's tester, tester.cpp:318-321)
+  int status() const { return pool_->status(); }
+
+  // From the next Predict on the mixers record instead of compute; results reach `sink` one chunk later.
+  // Every bit must be Predict -> Perceive -> Learn (the path that knows its bits: runner-utils.cpp:43-67, :223-322).
+  int BeginRunAhead(RunAheadSink* sink, uint64_t chunk_bits) {
+    if (ra_) return GMX_ERR_STATE;
+    Settle();
+    if (status()) return status();
+    // rows this bank has seen (Mixer::contexts_seen_ / GetMemoryUsage while the device runs behind)
+    seen_.assign(descs_.size(), std::vector<uint64_t>());
+    seen_count_.assign(descs_.size(), 0);
+    for (size_t j = 0; j < descs_.size(); ++j) seen_[j].assign(((size_t)descs_[j].table_size + 63) / 64, 0);
+    bool fresh = true;
+    for (size_t j = 0; j < descs_.size(); ++j) {
+      uint64_t sh[3];
+      memcpy(sh, &short_cache_[24 * j], 24);
+      fresh = fresh && sh[0] == 0;
+    }
+    if (!fresh || ever_ran_) {
+      Stage();
+      for (size_t j = 0; j < descs_.size(); ++j) {
+        auto& table = ltm_.mixers[memory_index_[j]].mixer_table;
+        for (size_t c = 0; c < table.size(); ++c)
+          if (table[c]) {
+            seen_[j][c >> 6] |= 1ull << (c & 63);
+            ++seen_count_[j];
+          }
+      }
+      Unstage();
+    }
+    int rc = pool_->Join(slot_, chunk_bits);
+    if (rc) return rc;
+    T_ = pool_->chunk_bits();
+    n_pad_ = pool_->n_pad_;
+    mask_words_ = pool_->mask_words_;
+    pool_->Records(slot_, &ra_pred_, &ra_mask_, &ra_ctx_, &ra_bits_);
+    t_ = 0;
+    recorded_ = false;
+    sink_ = sink;
+    ra_ = true;
+    ever_ran_ = true;
+    return GMX_OK;
+  }
+  // Hands in what is recorded, brings every outstanding result home (through the sink) and leaves the
+  // blackboard's mixer outputs as per-bit calls would have.
+  int EndRunAhead() {
+    if (!ra_) return GMX_OK;
+    int rc = SyncRunAhead();
+    pool_->Leave(slot_);
+    ra_ = false;
+    sink_ = nullptr;
+    return rc;
+  }
+  // The same without leaving run-ahead mode (a checkpoint in the middle of a file).
+  int SyncRunAhead() {
+    if (!ra_) return GMX_OK;
+    int rc = Flush();
+    if (rc == GMX_OK) rc = Flush();
+    return rc;
+  }
 
  private:
   friend class GpuMixer;
-  GpuMixerBank(ShortTermMemory& stm, LongTermMemory& ltm) : stm_(stm), ltm_(ltm) { ChainConsumers()[&ltm] = 1; }
+  GpuMixerBank(ShortTermMemory& stm, LongTermMemory& ltm) : stm_(stm), ltm_(ltm) {
+    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
+    pool_ = MixerPool::Installed();
+    if (!pool_) {
+      own_pool_.reset(new MixerPool(1));
+      pool_ = own_pool_.get();
+      ChainConsumers()[&ltm] = 1;  // (gmx_chain_forward pairs stream 0 of the two banks: banks of their own only)
+    }
+    slot_ = pool_->Acquire();
+    if (slot_ < 0) {
+      fprintf(stderr, "\ngmx::GpuMixer: the installed MixerPool has no free stream (%d in use)\n", pool_->n_streams());
+      abort();
+    }
+  }
   static std::map<const LongTermMemory*, std::weak_ptr<GpuMixerBank>>& Registry() {
     static std::map<const LongTermMemory*, std::weak_ptr<GpuMixerBank>> r;
     return r;
   }
-  [[noreturn]] static void Fatal(const char* what, int rc) {
+  void Check(const char* what, int rc) {
+    if (rc == GMX_OK) return;
+    if (pool_->shared_) {  // a process that hosts many compressors: report, do not take it down
+      std::lock_guard<std::mutex> lk(pool_->mu_);
+      pool_->Fail(what, rc);
+      return;
+    }
     fprintf(stderr, "\ngmx::GpuMixer: %s: %s %s\n(the mixers run on an MI355X through libgmxmix.so; there is no CPU fallback)\n",
             what, gmx_strerror(rc), rc == GMX_ERR_HIP ? gmx_last_error() : "");
     abort();
   }
-  static void Check(const char* what, int rc) {
-    if (rc != GMX_OK) Fatal(what, rc);
+  // a C-ABI call on the (possibly shared) group
+  template <class F>
+  void Call(const char* what, F f) {
+    if (pool_->status()) return;
+    int rc;
+    {
+      std::lock_guard<std::mutex> lk(pool_->mu_);
+      rc = f();
+    }
+    Check(what, rc);
   }
-  int Register(GpuMixer* m, int layer, unsigned table_size, float lr, int memory_index) {
+  int Register(GpuMixer* m, int layer, unsigned table_size, float lr, int memory_index, int weight_size) {
     gmx_mixer_desc d;
     d.layer = layer;
     d.table_size = table_size;
@@ -132,6 +480,7 @@ class GpuMixerBank {
     descs_.push_back(d);
     mixers_.push_back(m);
     memory_index_.push_back(memory_index);
+    weight_size_.push_back(weight_size);
     return (int)descs_.size() - 1;
   }
   // Device bank from what the constructors registered (all of them have run by the time any
@@ -145,8 +494,8 @@ class GpuMixerBank {
     t.skip_index = skip.data();
     t.n_mixers = (int32_t)descs_.size();
     t.mixers = descs_.data();
-    const char* dev = getenv("GMX_DEVICE");
-    Check("gmx_group_create", gmx_group_create(&group_, &t, 1, dev ? atoi(dev) : 0));
+    Call("gmx_group_create", [&] { return pool_->EnsureGroup(t); });
+    group_ = pool_->group();
     outputs_.assign(descs_.size(), 0.f);
     contexts_.assign(descs_.size(), 0u);
     short_cache_.assign(descs_.size() * 24, 0);
@@ -161,6 +510,7 @@ class GpuMixerBank {
   void Settle() {
     Ensure();
     if (!import_pending_) return;
+    if (ra_) SyncRunAhead();
     import_pending_ = false;
     std::vector<char> buf;
     auto put = [&buf](const void* p, size_t n) {
@@ -185,17 +535,21 @@ class GpuMixerBank {
         put(&table[c]->weights[0], 4 * table[c]->weights.size());
       }
     }
-    Check("gmx_bank_import", gmx_bank_import(group_, 0, buf.data(), buf.size(), short_in_.data(), short_in_.size()));
+    Call("gmx_bank_import",
+         [&] { return gmx_bank_import(group_, slot_, buf.data(), buf.size(), short_in_.data(), short_in_.size()); });
     staged_ = true;
+    ever_ran_ = true;
   }
   // Bank -> LongTermMemory::mixers (+ the 3 x u64 of every mixer), for the reference's writers.
   void Stage() {
     Settle();
+    if (ra_) SyncRunAhead();
     size_t nl = 0, ns = 0;
-    Check("gmx_bank_export", gmx_bank_export(group_, 0, nullptr, &nl, nullptr, &ns));
+    Call("gmx_bank_export", [&] { return gmx_bank_export(group_, slot_, nullptr, &nl, nullptr, &ns); });
     std::vector<char> l(nl ? nl : 1);
     short_cache_.assign(ns ? ns : 1, 0);
-    Check("gmx_bank_export", gmx_bank_export(group_, 0, l.data(), &nl, short_cache_.data(), &ns));
+    Call("gmx_bank_export", [&] { return gmx_bank_export(group_, slot_, l.data(), &nl, short_cache_.data(), &ns); });
+    if (status()) return;
     short_cache_.resize(ns);
     const char* p = l.data();
     for (size_t j = 0; j < descs_.size(); ++j) {
@@ -228,27 +582,106 @@ class GpuMixerBank {
   void ToBlackboard(ShortTermMemory& stm);
   void LearnAll(const ShortTermMemory& stm) {
     Settle();
-    Check("gmx_bank_learn", gmx_bank_learn(group_, 0, stm.new_bit));
+    if (ra_) {
+      if (!recorded_ || status()) return;  // (a Learn without its Predict has nothing to learn from)
+      recorded_ = false;
+      ra_bits_[t_] = (uint8_t)stm.new_bit;
+      const uint32_t* c = ra_ctx_ + (size_t)t_ * descs_.size();
+      for (size_t j = 0; j < descs_.size(); ++j) {  // Mixer::FindOrCreateMixerData's ++contexts_seen_ (mixer.cpp:39-49)
+        const uint32_t row = c[j] % descs_[j].table_size;
+        uint64_t& w = seen_[j][row >> 6];
+        const uint64_t bit = 1ull << (row & 63);
+        if (!(w & bit)) {
+          w |= bit;
+          ++seen_count_[j];
+        }
+      }
+      if (++t_ == T_) Flush();
+      return;
+    }
+    ever_ran_ = true;
+    Call("gmx_bank_learn", [&] { return gmx_bank_learn(group_, slot_, stm.new_bit); });
   }
   void CopyFrom(GpuMixerBank& o) {
+    if (o.ra_) o.SyncRunAhead();
+    if (ra_) SyncRunAhead();
     o.Settle();
     Ensure();
     import_pending_ = false;  // whatever LongTermMemory::Copy moves into the staging area is not ours to import
-    Check("gmx_bank_copy", gmx_bank_copy(group_, 0, o.group_, 0));
+    ever_ran_ = true;
+    if (o.pool_ == pool_) {
+      Call("gmx_bank_copy", [&] { return gmx_bank_copy(group_, slot_, o.group_, o.slot_); });
+    } else {  // two groups: both pools' calls held off, always in address order
+      MixerPool* a = pool_ < o.pool_ ? pool_ : o.pool_;
+      MixerPool* b = pool_ < o.pool_ ? o.pool_ : pool_;
+      int rc;
+      {
+        std::lock_guard<std::mutex> la(a->mu_);
+        std::lock_guard<std::mutex> lb(b->mu_);
+        rc = gmx_bank_copy(group_, slot_, o.group_, o.slot_);
+      }
+      Check("gmx_bank_copy", rc);
+    }
+    if (ra_) {  // the copied bank's rows are this bank's now
+      seen_ = o.seen_.empty() ? seen_ : o.seen_;
+      seen_count_ = o.seen_count_.empty() ? seen_count_ : o.seen_count_;
+    }
+  }
+  unsigned long long MemoryUsage(int index) {
+    Settle();
+    if (ra_)  // mixer.cpp:197-205 from the host's own count of rows (the device runs a chunk behind)
+      return 29ull + seen_count_[index] * (unsigned long long)(weight_size_[index] * 4 + 12) +
+             8ull * descs_[index].table_size;
+    uint64_t v = 0;
+    Call("gmx_bank_memory_usage", [&] { return gmx_bank_memory_usage(group_, slot_, index, &v); });
+    return v;
+  }
+  // One round of the ring: the chunk recorded so far goes to the device, the chunk before it comes back.
+  int Flush() {
+    MixerPool::View v;
+    int rc = pool_->Arrive(slot_, t_, &v);
+    t_ = 0;
+    if (rc) return rc;
+    if (v.n) {
+      const int M = (int)descs_.size();
+      if (sink_) sink_->Drain(v.p, v.bits, v.out, M, v.n);
+      // mixer.cpp:99-105: where the Mixer::Predict calls of the newest bit left their results
+      const float* o = v.out + (size_t)(v.n - 1) * M;
+      size_t j = 0;
+      for (int k = 0; k < stm_.num_layer0_mixers; ++k) stm_.mixer_layer0_outputs[k] = o[j++];
+      for (int k = 0; k < stm_.num_layer1_mixers; ++k) stm_.mixer_layer1_outputs[k] = o[j++];
+      if (j < (size_t)M) stm_.final_mixer_output = o[j];
+    }
+    pool_->Records(slot_, &ra_pred_, &ra_mask_, &ra_ctx_, &ra_bits_);
+    return GMX_OK;
   }
 
   ShortTermMemory& stm_;
   LongTermMemory& ltm_;
+  std::unique_ptr<MixerPool> own_pool_;
+  MixerPool* pool_ = nullptr;
+  int slot_ = 0;
   gmx_group* group_ = nullptr;
   std::vector<gmx_mixer_desc> descs_;
   std::vector<GpuMixer*> mixers_;
-  std::vector<int> memory_index_;
+  std::vector<int> memory_index_, weight_size_;
   std::vector<float> outputs_;
   std::vector<uint32_t> contexts_;
   std::vector<float> chain_pred_;
   std::vector<uint8_t> chain_act_;
   std::vector<char> short_cache_, short_in_;
-  bool import_pending_ = false, staged_ = false;
+  bool import_pending_ = false, staged_ = false, ever_ran_ = false;
+  // run-ahead
+  bool ra_ = false, recorded_ = false;
+  RunAheadSink* sink_ = nullptr;
+  uint64_t T_ = 0, t_ = 0;
+  int n_pad_ = 0, mask_words_ = 0;
+  float* ra_pred_ = nullptr;
+  uint32_t* ra_mask_ = nullptr;
+  uint32_t* ra_ctx_ = nullptr;
+  uint8_t* ra_bits_ = nullptr;
+  std::vector<std::vector<uint64_t>> seen_;
+  std::vector<uint64_t> seen_count_;
 };
 
 class GpuMixer : public Model {
@@ -259,10 +692,19 @@ class GpuMixer : public Model {
            bool enable_analysis)
       : context_(context), bank_(GpuMixerBank::For(short_term_memory, long_term_memory)) {
     // mixer.cpp:12-15: the registrations Mixer::Mixer makes
-    short_term_memory.AddMixer(description, layer_number, enable_analysis, this);
+    const int output_index = short_term_memory.AddMixer(description, layer_number, enable_analysis, this);
     int memory_index = (int)long_term_memory.mixers.size();
     long_term_memory.mixers.push_back(MixerMemory(table_size));
-    index_ = bank_->Register(this, layer_number, table_size, learning_rate, memory_index);
+    int weight_size;  // mixer.cpp:17-26
+    if (layer_number == 0)
+      weight_size = short_term_memory.num_predictions + output_index;
+    else if (layer_number == 1)
+      weight_size = short_term_memory.num_layer0_mixers + output_index +
+                    (int)short_term_memory.models_with_skip_connection.size();
+    else
+      weight_size = short_term_memory.num_layer0_mixers + short_term_memory.num_layer1_mixers +
+                    (int)short_term_memory.models_with_skip_connection.size();
+    index_ = bank_->Register(this, layer_number, table_size, learning_rate, memory_index, weight_size);
   }
   void Predict(ShortTermMemory& short_term_memory, const LongTermMemory&) override {
     if (index_ == 0) bank_->PredictAll(short_term_memory);
@@ -290,10 +732,7 @@ class GpuMixer : public Model {
   }
   // mixer.cpp:197-205
   unsigned long long GetMemoryUsage(const ShortTermMemory&, const LongTermMemory&) override {
-    bank_->Settle();
-    uint64_t v = 0;
-    GpuMixerBank::Check("gmx_bank_memory_usage", gmx_bank_memory_usage(bank_->group_, 0, index_, &v));
-    return v;
+    return bank_->MemoryUsage(index_);
   }
   unsigned int context() const { return context_; }
 
@@ -305,27 +744,48 @@ class GpuMixer : public Model {
 
 inline void GpuMixerBank::PredictAll(ShortTermMemory& stm) {
   Settle();
+  if (status()) return;
+  if (ra_) {
+    // Mixer::Predict x 33, recorded: the raw blackboard, active_models as a mask, the contexts read now
+    if (recorded_) {  // a Predict whose bit was never learned: not a path that runs ahead
+      Check("run-ahead needs Predict -> Perceive -> Learn for every bit", GMX_ERR_STATE);
+      return;
+    }
+    const int N = stm.num_predictions;
+    memcpy(ra_pred_ + (size_t)t_ * n_pad_, &stm.predictions[0], 4 * (size_t)N);
+    uint32_t* m = ra_mask_ + (size_t)t_ * mask_words_;
+    for (int w = 0; w < mask_words_; ++w) m[w] = 0;
+    for (int idx : stm.active_models) m[idx >> 5] |= 1u << (idx & 31);
+    uint32_t* c = ra_ctx_ + (size_t)t_ * mixers_.size();
+    for (size_t j = 0; j < mixers_.size(); ++j) c[j] = mixers_[j]->context();
+    recorded_ = true;
+    return;
+  }
   for (size_t j = 0; j < mixers_.size(); ++j) contexts_[j] = mixers_[j]->context();  // read at call time
   static_assert(sizeof(int) == sizeof(int32_t), "active_models is passed as it stands");
   float p = 0.5f;
   ChainProducer* ind = nullptr;
   {
+    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
     auto it = ChainProducers().find(&ltm_);
     if (it != ChainProducers().end() && it->second->Pending()) ind = it->second;
   }
+  ever_ran_ = true;
   if (ind) {
     // the Indirect models' Predict of this bit is still to run: both banks in one round trip
     chain_pred_.resize(128);  // two slots for each of at most 64 models (gmx_indirect_create's limit)
     chain_act_.resize(128);
-    Check("gmx_chain_forward",
-          gmx_chain_forward(ind->Handle(), group_, 0, ind->Contexts(), ind->BitContext(), &stm.predictions[0],
-                            stm.active_models.data(), (int)stm.active_models.size(), contexts_.data(), &p,
-                            outputs_.data(), chain_pred_.data(), chain_act_.data()));
+    Call("gmx_chain_forward", [&] {
+      return gmx_chain_forward(ind->Handle(), group_, slot_, ind->Contexts(), ind->BitContext(), &stm.predictions[0],
+                               stm.active_models.data(), (int)stm.active_models.size(), contexts_.data(), &p,
+                               outputs_.data(), chain_pred_.data(), chain_act_.data());
+    });
     ind->Deliver(stm, chain_pred_.data(), chain_act_.data());
   } else {
-    Check("gmx_bank_forward",
-          gmx_bank_forward(group_, 0, &stm.predictions[0], stm.active_models.data(), (int)stm.active_models.size(),
-                           contexts_.data(), &p, outputs_.data()));
+    Call("gmx_bank_forward", [&] {
+      return gmx_bank_forward(group_, slot_, &stm.predictions[0], stm.active_models.data(),
+                              (int)stm.active_models.size(), contexts_.data(), &p, outputs_.data());
+    });
   }
   // mixer.cpp:99-105: where each Mixer::Predict leaves its result
   size_t j = 0;
@@ -350,6 +810,7 @@ class GpuIndirect;
 class GpuIndirectBank : public ChainProducer {
  public:
   static std::shared_ptr<GpuIndirectBank> For(ShortTermMemory& stm, LongTermMemory& ltm) {
+    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
     auto& reg = Registry();
     auto it = reg.find(&ltm);
     if (it != reg.end())
@@ -360,6 +821,7 @@ class GpuIndirectBank : public ChainProducer {
   }
   ~GpuIndirectBank() {
     if (h_) gmx_indirect_destroy(h_);
+    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
     Registry().erase(&ltm_);
     ChainProducers().erase(&ltm_);
   }
@@ -379,7 +841,10 @@ class GpuIndirectBank : public ChainProducer {
 
  private:
   friend class GpuIndirect;
-  GpuIndirectBank(ShortTermMemory& stm, LongTermMemory& ltm) : stm_(stm), ltm_(ltm) { ChainProducers()[&ltm] = this; }
+  GpuIndirectBank(ShortTermMemory& stm, LongTermMemory& ltm) : stm_(stm), ltm_(ltm) {
+    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
+    ChainProducers()[&ltm] = this;
+  }
   static std::map<const LongTermMemory*, std::weak_ptr<GpuIndirectBank>>& Registry() {
     static std::map<const LongTermMemory*, std::weak_ptr<GpuIndirectBank>> r;
     return r;
@@ -567,7 +1032,12 @@ class GpuIndirect : public Model {
 inline void GpuIndirectBank::PredictAll(ShortTermMemory& stm) {
   Settle();
   for (size_t i = 0; i < models_.size(); ++i) contexts_[i] = models_[i]->context();
-  if (ChainFused() && ChainConsumers().count(&ltm_)) {
+  bool fused = ChainFused();
+  if (fused) {
+    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
+    fused = ChainConsumers().count(&ltm_) != 0;
+  }
+  if (fused) {
     // this Predictor's mixers are on the device too and theirs is the next Predict (predictor.cpp:24-28):
     // they take this bank along (ChainProducer)
     pending_ = true;

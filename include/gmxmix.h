@@ -79,6 +79,10 @@ const char* gmx_strerror(int status);
 const char* gmx_last_error(void);          /* text of the last GMX_ERR_HIP on this thread */
 int gmx_device_count(int* count);          /* gfx950 devices visible */
 const char* gmx_build_info(void);          /* arch, flags, version */
+/* PCI address of a device ("0000:c1:00.0", len >= 13): the key of /sys/bus/pci/devices/<id>/numa_node, so that
+ * the host threads feeding a device (the reference's feature models, one Predictor per stream) can be kept on
+ * the cores next to it. */
+int gmx_device_pci_bus_id(int device, char* buf, size_t len);
 
 /* ---- group: replaces Predictor::AddMixers' 33 objects (predictor.cpp:251-358) ---------- */
 int gmx_group_create(gmx_group** out, const gmx_topology* topo, int n_streams, int device);
@@ -155,6 +159,12 @@ int gmx_batch_fill_synthetic(gmx_batch* b, uint64_t n_bits, uint64_t seed, uint6
  * group's stream; kernel_ms (nullable) receives the kernel's duration measured with HIP
  * events on that stream, which makes the call synchronous. */
 int gmx_group_run(gmx_group* g, gmx_batch* b, uint64_t n_bits, int learn, float* kernel_ms);
+
+/* The same for streams that stand at different lengths -- S files compressed side by side
+ * (runner-utils.cpp:43-67 once per file) end at different bits: stream s runs bits [0, n_bits[s]) of its
+ * records, 0 = the stream sits this launch out.  Neighbouring streams with equal counts share a launch.
+ * Asynchronous on the group's stream. */
+int gmx_group_run_ragged(gmx_group* g, gmx_batch* b, const uint64_t* n_bits /* [S] */, int learn);
 
 /* ---- persistence ------------------------------------------ */
 /* Byte-compatible with the reference: *short_bytes = Mixer::WriteToDisk of every mixer in

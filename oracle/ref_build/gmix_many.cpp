@@ -1,0 +1,71 @@
+// gmix_many.cpp -- TEST / BENCH DRIVER around gmx::BatchedCompressFiles (gmix_amd/host/gmx_batched.h): many files
+// compressed side by side, one reference Predictor (and host thread) per file, all mixers in one device group.
+// Linked by oracle/ref_build/Makefile against the reference's own translation units (feature models, coder,
+// runner-utils) with Predictor::AddMixers constructing gmx::GpuMixer -- the reference calls the product.
+//
+// usage: gmix_many [-T chunk_bits] [-n bytes] [--no-pin] <out dir> <input file>...
+//   each input is compressed to <out dir>/<index>.gmix exactly as `gmix -c` would (runner-utils.cpp:88-121);
+//   -n limits every input to its first n bytes (written to <out dir>/<index>.in first).
+//   One JSON line on stdout: per-file sizes and times, the wall time of the compression phase, bits, launches.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "gmx_batched.h"
+
+int main(int argc, char** argv) {
+  gmx::BatchedOptions opt;
+  unsigned long long limit = 0;
+  int a = 1;
+  for (; a < argc && argv[a][0] == '-'; ++a) {
+    if (!strcmp(argv[a], "-T") && a + 1 < argc)
+      opt.chunk_bits = strtoull(argv[++a], 0, 0);
+    else if (!strcmp(argv[a], "-n") && a + 1 < argc)
+      limit = strtoull(argv[++a], 0, 0);
+    else if (!strcmp(argv[a], "--no-pin"))
+      opt.pin_threads = false;
+    else
+      break;
+  }
+  if (argc - a < 2) {
+    fprintf(stderr, "usage: %s [-T chunk_bits] [-n bytes] [--no-pin] <out dir> <input file>...\n", argv[0]);
+    return 2;
+  }
+  const std::string out_dir = argv[a++];
+  std::filesystem::create_directories(out_dir);
+  std::vector<gmx::BatchedJob> jobs;
+  for (int k = 0; a < argc; ++a, ++k) {
+    gmx::BatchedJob j;
+    j.input_path = argv[a];
+    if (limit) {
+      std::ifstream in(argv[a], std::ios::binary);
+      std::vector<char> head(limit);
+      in.read(head.data(), limit);
+      head.resize((size_t)in.gcount());
+      j.input_path = out_dir + "/" + std::to_string(k) + ".in";
+      std::ofstream(j.input_path, std::ios::binary).write(head.data(), head.size());
+    }
+    j.output_path = out_dir + "/" + std::to_string(k) + ".gmix";
+    jobs.push_back(j);
+  }
+  gmx::BatchedStats st;
+  const int failed = gmx::BatchedCompressFiles(jobs, opt, &st);
+  unsigned long long in_bytes = 0, out_bytes = 0;
+  printf("{\"files\": %zu, \"failed\": %d, \"chunk_bits\": %llu, \"wall_seconds\": %.6f, \"build_seconds\": %.3f, "
+         "\"launches\": %llu, \"device_bits\": %llu, \"pinned_threads\": %d, \"jobs\": [",
+         jobs.size(), failed, (unsigned long long)opt.chunk_bits, st.wall_seconds, st.build_seconds,
+         (unsigned long long)st.launches, (unsigned long long)st.bits, st.pinned_threads);
+  for (size_t k = 0; k < jobs.size(); ++k) {
+    printf("%s{\"in\": %llu, \"out\": %llu, \"status\": %d, \"seconds\": %.6f}", k ? ", " : "", jobs[k].input_bytes,
+           jobs[k].output_bytes, jobs[k].status, jobs[k].seconds);
+    in_bytes += jobs[k].input_bytes;
+    out_bytes += jobs[k].output_bytes;
+  }
+  printf("], \"input_bytes\": %llu, \"output_bytes\": %llu, \"bits_per_second\": %.1f}\n", in_bytes, out_bytes,
+         st.wall_seconds > 0 ? 8.0 * in_bytes / st.wall_seconds : 0.0);
+  return failed ? 1 : 0;
+}
