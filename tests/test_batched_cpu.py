@@ -1,0 +1,56 @@
+"""The run-ahead compressor's HOST logic without a GPU (gmix_amd/host/gmx_batched.h + the run-ahead mode and
+MixerPool of gmx_model_adapter.h): the reference's CLI, tester and a many-file driver built on it, the C-ABI calls
+answered by the oracle (tests/cpp/gmx_abi_oracle_shim.c -- test-only; the product has no CPU path), beside the
+stock build.  What is checked here: records written at the right bit, chunks handed in and drained in order
+through the two-batch ring, ragged ends, the coder fed in order, the analysis rows, thread hand-offs.  The
+same comparisons against libgmxmix.so on an MI355X: tests/test_gpu_batched.py."""
+import os
+
+import pytest
+
+from batched_common import REF, compress_pair, corpus, gmix, need, run_many, same_outputs
+from dropin_common import compare, run_all
+
+
+def _skip_unless(*exes):
+    for exe in exes:
+        if not os.path.exists(os.path.join(REF, exe)):
+            pytest.skip(f"oracle/_ref/{exe} not built (needs /root/reference: make -C oracle/ref_build batched)")
+
+
+def test_batched_cli_writes_the_stock_file_and_tables(tmp_path):
+    """5 000 bytes: 19+ chunks of 2 048 bits and a ragged last one; analysis on (40 bits per row: 1 000 rows whose
+    final-mixer column comes from the returned chunks)."""
+    _skip_unless("gmix_strict", "gmix_batched_shim")
+    src, stock, batched = compress_pair("gmix_strict", "gmix_batched_shim", corpus(5000, 777), tmp_path)
+    same_outputs(stock, batched)
+    gmix("gmix_strict", "-d", batched / "c", stock / "back", stock)
+    assert (stock / "back").read_bytes() == src.read_bytes()
+
+
+@pytest.mark.parametrize("chunk", [8, 72, 4096])
+def test_many_files_ragged_lengths(tmp_path, chunk):
+    """Three Predictors on three threads share one group; files of 1 / 613 / 1 500 bytes end in different rounds
+    (a stream that has left must not hold the others up), chunks of one byte up to more than the longest file."""
+    _skip_unless("gmix_strict", "gmix_many_shim")
+    files = []
+    for k, n in enumerate((1, 613, 1500)):
+        f = tmp_path / f"f{k}"
+        f.write_bytes(corpus(n, 4000 * k))
+        files.append(f)
+    st = run_many("gmix_many_shim", files, tmp_path / "out", chunk)
+    assert st["failed"] == 0 and st["device_bits"] == 8 * (1 + 613 + 1500)
+    for k, f in enumerate(files):
+        gmix("gmix_strict", "-c", f, tmp_path / f"ref{k}", tmp_path)
+        assert (tmp_path / f"ref{k}").read_bytes() == (tmp_path / "out" / f"{k}.gmix").read_bytes(), f"file {k}"
+
+
+@pytest.mark.slow
+def test_reference_tester_with_batched_compression(tmp_path):
+    """The reference's tester with RunCompression running ahead: TestCompression goes through
+    gmx::BatchedCompress, the restart / Copy / decode tests through the per-bit path on the bank the batch
+    left behind -- the tester itself compares their files with the batched one, and everything it leaves equals
+    the stock build's."""
+    _skip_unless("ref_tester_strict", "ref_tester_batched_shim")
+    stock, batched = run_all([("ref_tester_strict", 300), ("ref_tester_batched_shim", 300)], 1200, tmp_path)
+    compare(stock, batched)

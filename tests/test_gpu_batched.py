@@ -1,0 +1,79 @@
+"""The run-ahead compressor on an MI355X (BASELINE.json configs[2] / [3]): the reference's own
+88 feature models and coder on the host cores, running ahead of the 33 mixers, which libgmxmix.so takes in
+double-buffered batches (gmix_amd/host/gmx_batched.h).  Built by oracle/ref_build/Makefile (`batched`) from the
+reference's sources where they lie, with Predictor::AddMixers constructing gmx::GpuMixer and RunCompression calling
+gmx::BatchedCompress: the reference calls the product.  Every file must equal the stock build's."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+from batched_common import REF, compress_pair, corpus, gmix, need, run_many, same_outputs
+from dropin_common import compare, run_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batched_compress_100k_equals_stock_and_round_trips(gpu, tmp_path):
+    """`gmix -c` of 100 000 bytes of text: 391 chunks of 2 048 bits through the two-batch ring.  Same compressed
+    bytes as the stock build, same analysis tables (1 000 rows whose final-mixer entropy is computed from the
+    returned chunks), and the STOCK build's `gmix -d` restores the input from the run-ahead compressor's file."""
+    need("gmix_strict", "gmix_batched")
+    src, stock, batched = compress_pair("gmix_strict", "gmix_batched", corpus(100000), tmp_path)
+    same_outputs(stock, batched)
+    gmix("gmix_strict", "-d", batched / "c", stock / "back", stock)
+    assert (stock / "back").read_bytes() == src.read_bytes()
+
+
+def test_reference_tester_with_batched_compression_equals_stock(gpu, tmp_path):
+    """The reference's five tests with RunCompression running ahead on the device: TestCompression is batched, the
+    restart / Copy / decode / generation tests go per bit (sessions) on banks that batches have been through; the
+    tester compares their files with the batched one itself, and all it leaves equals the stock build's."""
+    need("ref_tester_strict", "ref_tester_batched")
+    da, db = run_pair("ref_tester_strict", "ref_tester_batched", 30000, 2000, tmp_path)
+    compare(da, db)
+
+
+def test_64_files_side_by_side_equal_stock(gpu, tmp_path):
+    """64 Predictors on 64 host threads, their mixers 64 streams of ONE gmx_group, one launch per 2 048-bit chunk for
+    all of them; files of 30 000 .. 36 300 bytes starting at different places of the corpus, so they end in
+    different rounds.  Every output is the stock build's `gmix -c` of the same file."""
+    need("gmix_strict", "gmix_many")
+    files = []
+    for k in range(64):
+        f = tmp_path / f"f{k}"
+        f.write_bytes(corpus(30000 + 100 * k, 1531 * k))
+        files.append(f)
+    st = run_many("gmix_many", files, tmp_path / "out", 2048)
+    assert st["failed"] == 0 and st["files"] == 64
+    assert st["device_bits"] == 8 * sum(30000 + 100 * k for k in range(64))
+
+    def stock(k):
+        d = tmp_path / f"s{k}"
+        d.mkdir()
+        gmix("gmix_strict", "-c", files[k], d / "c", d)
+        return (d / "c").read_bytes()
+
+    with ThreadPoolExecutor(16) as ex:
+        refs = list(ex.map(stock, range(64)))
+    for k in range(64):
+        assert refs[k] == (tmp_path / "out" / f"{k}.gmix").read_bytes(), f"file {k} differs from gmix_strict -c"
+    print(f"64 files: {st['bits_per_second']:.3g} bits/s aggregate, {st['wall_seconds']:.2f} s, "
+          f"{st['launches']} launches, {st['pinned_threads']} threads pinned")
+
+
+@pytest.mark.parametrize("chunk", [8, 1000])
+def test_small_chunks_and_ragged_ends(gpu, tmp_path, chunk):
+    """Chunks of one byte (every launch is a ragged one at the end) and of 1 000 bits for files of 1 .. 2 000 bytes."""
+    need("gmix_strict", "gmix_many")
+    sizes = (1, 300, 2000, 2000, 777)
+    files = []
+    for k, n in enumerate(sizes):
+        f = tmp_path / f"f{k}"
+        f.write_bytes(corpus(n, 5000 * k))
+        files.append(f)
+    st = run_many("gmix_many", files, tmp_path / "out", chunk)
+    assert st["failed"] == 0 and st["device_bits"] == 8 * sum(sizes)
+    for k, f in enumerate(files):
+        gmix("gmix_strict", "-c", f, tmp_path / f"ref{k}", tmp_path)
+        assert (tmp_path / f"ref{k}").read_bytes() == (tmp_path / "out" / f"{k}.gmix").read_bytes(), f"file {k}"
