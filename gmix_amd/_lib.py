@@ -116,6 +116,7 @@ def lib():
     L.gmx_ind_batch_wait.argtypes = [vp]
     L.gmx_ind_batch_fill_synthetic.argtypes = [vp, u64, u64, u64, vp]
     L.gmx_indirect_run.argtypes = [vp, vp, u64, i32, vp, C.POINTER(C.c_float)]
+    L.gmx_indirect_run_ragged.argtypes = [vp, vp, C.POINTER(u64), i32, vp]
     L.gmx_indirect_export.argtypes = [vp, i32, vp, C.POINTER(C.c_size_t)]
     L.gmx_indirect_import.argtypes = [vp, i32, vp, C.c_size_t]
     L.gmx_indirect_copy.argtypes = [vp, i32, vp, i32]
@@ -141,6 +142,7 @@ def lib():
     L.gmx_lstm_batch_download.argtypes = [vp, u64]
     L.gmx_lstm_batch_wait.argtypes = [vp]
     L.gmx_lstm_run.argtypes = [vp, vp, u64, i32, C.POINTER(C.c_float)]
+    L.gmx_lstm_run_ragged.argtypes = [vp, vp, C.POINTER(u64), i32]
     L.gmx_lstm_forward.argtypes = [vp, i32, i32, vp, vp, C.POINTER(u32)]
     L.gmx_lstm_perceive.argtypes = [vp, i32, i32]
     L.gmx_lstm_feed.argtypes = [vp, vp, u64, vp, i32, i32, vp, i32]
@@ -186,13 +188,13 @@ ABI_SYMBOLS = [
     "gmx_indirect_learn", "gmx_ind_batch_create", "gmx_ind_batch_destroy", "gmx_ind_batch_max_bits",
     "gmx_ind_batch_contexts", "gmx_ind_batch_bit_contexts", "gmx_ind_batch_bits",
     "gmx_ind_batch_predictions", "gmx_ind_batch_active", "gmx_ind_batch_upload", "gmx_ind_batch_download",
-    "gmx_ind_batch_wait", "gmx_ind_batch_fill_synthetic", "gmx_indirect_run", "gmx_indirect_export",
+    "gmx_ind_batch_wait", "gmx_ind_batch_fill_synthetic", "gmx_indirect_run", "gmx_indirect_run_ragged", "gmx_indirect_export",
     "gmx_indirect_import", "gmx_indirect_copy", "gmx_indirect_memory_usage",
     "gmx_lstm_create", "gmx_lstm_destroy", "gmx_lstm_n_streams", "gmx_lstm_bank_bytes", "gmx_lstm_reset",
     "gmx_lstm_sync", "gmx_lstm_set_weights", "gmx_lstm_get_weights", "gmx_lstm_batch_create",
     "gmx_lstm_batch_destroy", "gmx_lstm_batch_ppm", "gmx_lstm_batch_bytes", "gmx_lstm_batch_predictions",
     "gmx_lstm_batch_active", "gmx_lstm_batch_contexts", "gmx_lstm_batch_upload", "gmx_lstm_batch_download",
-    "gmx_lstm_batch_wait", "gmx_lstm_run", "gmx_lstm_forward", "gmx_lstm_perceive", "gmx_lstm_feed",
+    "gmx_lstm_batch_wait", "gmx_lstm_run", "gmx_lstm_run_ragged", "gmx_lstm_forward", "gmx_lstm_perceive", "gmx_lstm_feed",
     "gmx_lstm_export", "gmx_lstm_import", "gmx_lstm_copy", "gmx_lstm_memory_usage",
     "gmx_group_set_cu_mask", "gmx_indirect_set_cu_mask", "gmx_lstm_set_cu_mask",
 ]

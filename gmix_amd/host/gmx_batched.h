@@ -125,13 +125,28 @@ class BatchedCompressor : public RunAheadSink {
       // the Predictor keeps averaging per bit but leaves the rows to this object (they need the device's outputs)
       p_->SetAnalysisFrequency(kNever);
       const int N = stm.num_predictions;
+      const std::vector<int> ind_slots = bank_->IndirectSlots();
+      const int lstm_slot = bank_->LstmSlot();
       for (int i = 0; i < (int)stm.model_enable_analysis.size(); ++i) {
         if (!stm.model_enable_analysis[i]) continue;
         analysed_.push_back(i);
+        Source src;
+        src.column = (int)analysed_.size() - 1;
         if (i >= N) {
-          on_device_.push_back((int)analysed_.size() - 1);
-          ema_.push_back(stm.entropy[i]);
+          src.kind = kMixer;
+          src.index = i - N;
+        } else if (i == lstm_slot) {
+          src.kind = kLstm;
+          wants_models_ = true;
+        } else {
+          auto it = std::find(ind_slots.begin(), ind_slots.end(), i);
+          if (it == ind_slots.end()) continue;  // a feature model on the host: the Predictor's own average is right
+          src.kind = kIndirect;
+          src.index = (int)(it - ind_slots.begin());
+          wants_models_ = true;
         }
+        src.ema = stm.entropy[i];
+        on_device_.push_back(src);
       }
     }
     uint64_t chunk = opt_.chunk_bits < 8 ? 8 : opt_.chunk_bits & ~7ull;
@@ -166,7 +181,7 @@ class BatchedCompressor : public RunAheadSink {
     rc = bank_->EndRunAhead();
     if (rc == GMX_OK) rc = bank_->status();
     if (F_ > 0) {
-      for (size_t k = 0; k < on_device_.size(); ++k) stm.entropy[analysed_[on_device_[k]]] = ema_[k];
+      for (const Source& src : on_device_) stm.entropy[analysed_[src.column]] = src.ema;
       p_->SetAnalysisFrequency(sample_frequency);
     }
     if (rc) return rc;
@@ -176,13 +191,24 @@ class BatchedCompressor : public RunAheadSink {
   }
 
   // RunAheadSink: a chunk is back
-  void Drain(const float* p, const uint8_t* bits, const float* outputs, int n_mixers, uint64_t n) override {
-    const int N = bank_->stm().num_predictions;
-    for (uint64_t i = 0; i < n; ++i) {
-      enc_.Encode(bits[i], p[i]);
+  bool WantsModels() const override { return wants_models_; }
+  void Drain(const RunAheadView& v) override {
+    for (uint64_t i = 0; i < v.n; ++i) {
+      enc_.Encode(v.bits[i], v.p[i]);
       if (F_ > 0) {
-        for (size_t k = 0; k < on_device_.size(); ++k)  // Predictor::UpdateEntropy (predictor.cpp:439-469)
-          ema_[k] = Average(ema_[k], outputs[i * n_mixers + (analysed_[on_device_[k]] - N)], bits[i]);
+        for (Source& src : on_device_) {  // Predictor::UpdateEntropy (predictor.cpp:439-469) on what the device produced
+          float x;
+          if (src.kind == kMixer) {
+            x = v.outputs[i * v.n_mixers + src.index];
+          } else if (src.kind == kIndirect) {
+            // (a model that stayed silent left the zero Predictor::Predict had put there, predictor.cpp:362-365)
+            const size_t q = i * 2 * (size_t)v.n_ind + src.index;
+            x = v.ind_active[q] ? v.ind_pred[q] : 0.0f;
+          } else {
+            x = v.lstm_active[i] ? v.lstm_pred[i] : 0.0f;  // [byte][8] is bit order
+          }
+          src.ema = Average(src.ema, x, v.bits[i]);
+        }
         if (!rows_.empty() && rows_.front().bit == drained_) {
           WriteRow(rows_.front());
           rows_.pop_front();
@@ -234,7 +260,7 @@ class BatchedCompressor : public RunAheadSink {
     rows_.push_back(std::move(r));
   }
   void WriteRow(Row& r) {
-    for (size_t k = 0; k < on_device_.size(); ++k) r.entropy[on_device_[k]] = ema_[k];
+    for (const Source& src : on_device_) r.entropy[src.column] = src.ema;
     std::ofstream entropy_file("analysis/entropy.tsv", std::ios::app);
     std::ofstream memory_file("analysis/memory.tsv", std::ios::app);
     entropy_file << r.bits_seen;
@@ -253,9 +279,16 @@ class BatchedCompressor : public RunAheadSink {
   BatchedOptions opt_;
   std::shared_ptr<GpuMixerBank> bank_;
   int F_ = 0;
-  std::vector<int> analysed_;   // entropy indices with analysis on, ascending (the tables' columns)
-  std::vector<int> on_device_;  // positions in analysed_ that are mixers
-  std::vector<double> ema_;     // their averages, up to the last bit that came back
+  enum Kind { kMixer, kIndirect, kLstm };
+  struct Source {   // an analysed entry whose values come from the device
+    int column = 0;   // position in analysed_
+    Kind kind = kMixer;
+    int index = 0;    // mixer number / position in GpuMixerBank::IndirectSlots()
+    double ema = 0;   // its average, up to the last bit that came back
+  };
+  std::vector<int> analysed_;       // entropy indices with analysis on, ascending (the tables' columns)
+  std::vector<Source> on_device_;
+  bool wants_models_ = false;
   std::deque<Row> rows_;
   uint64_t recorded_ = 0, drained_ = 0;
 };

@@ -58,35 +58,17 @@
 namespace gmx {
 
 class GpuMixer;
+class GpuMixerBank;
+class GpuIndirect;
+class GpuIndirectBank;
+class GpuLstmModel;
 
-// The Indirect models' bank of a Predictor, as the mixers' bank of the same Predictor sees it.  The last
-// feature model in front of the mixers is an Indirect model (predictor.cpp:24-28), so its bank does not run at
-// its own Predict but hands contexts to the first mixer's: gmx_chain_forward then takes both banks through
-// ONE host round trip (the Indirect wave rings the mixers' wave itself).  GMX_CHAIN_FUSED=0 switches back to
-// one call per bank.
-struct ChainProducer {
-  virtual ~ChainProducer() {}
-  virtual bool Pending() const = 0;
-  virtual gmx_indirect* Handle() = 0;
-  virtual const uint32_t* Contexts() const = 0;
-  virtual uint32_t BitContext() const = 0;
-  // the results go where 41 x Indirect::Predict would have left them; nothing is pending afterwards
-  virtual void Deliver(ShortTermMemory& stm, const float* pred, const uint8_t* active) = 0;
-};
 // Process-wide tables of the adapters.  The reference lets several Predictors live in one process
 // (runner-utils.cpp:291-292); here they may also be built and run on different threads (one file per thread,
 // MixerPool below), so every access goes through AdapterMutex().
 inline std::recursive_mutex& AdapterMutex() {
   static std::recursive_mutex m;
   return m;
-}
-inline std::map<const LongTermMemory*, ChainProducer*>& ChainProducers() {
-  static std::map<const LongTermMemory*, ChainProducer*> r;
-  return r;
-}
-inline std::map<const LongTermMemory*, int>& ChainConsumers() {  // Predictors whose mixers are on the device
-  static std::map<const LongTermMemory*, int> r;
-  return r;
 }
 inline bool ChainFused() {
   static const bool on = [] {
@@ -99,28 +81,44 @@ inline bool ChainFused() {
 // ------------------------------------------------------------------------------------------------
 // Run-ahead.  In compression and training the coded bits are known in advance and no feature model ever reads a
 // mixer output (predictor.cpp:360-387 only hands them to later mixers, the final squash and the analysis), so
-// the 88 feature models of a Predictor can run T bits ahead while the device mixes the T bits before: the
-// mixers' Predict then only RECORDS its inputs {predictions, active_models, 33 contexts} and Learn the coded
-// bit, straight into the pinned arrays of a gmx_batch; a full chunk is uploaded and run behind the chunk
-// before it (two batches used alternately) and its probabilities come back one
-// chunk later, in order, to whoever consumes them (the arithmetic coder: gmx_batched.h).
+// the host-side feature models of a Predictor can run T bits ahead while the device works on the T bits before:
+// the device-side models' Predict then only RECORDS its inputs and Learn the coded bit, straight into the pinned
+// arrays of the banks' batches -- the mixers {predictions, active_models, 33 contexts, bit}, the Indirect models
+// {41 contexts, bit_context, bit}, the LSTM {PPM byte distribution, byte} -- a full chunk is uploaded and run
+// behind the chunk before it (two sets of batches used alternately) and its
+// probabilities come back one chunk later, in order, to whoever consumes them (the arithmetic coder:
+// gmx_batched.h).
 // ------------------------------------------------------------------------------------------------
+struct RunAheadView {
+  // n bits of one stream, oldest first
+  uint64_t n = 0;
+  const float* p = nullptr;         // [n] what Predictor::Predict() would have returned
+  const uint8_t* bits = nullptr;    // [n] the bit that was then perceived
+  const float* outputs = nullptr;   // [n][n_mixers] every mixer's output (logit domain)
+  int n_mixers = 0;
+  // with the Indirect models / the LSTM on the device too, and only when asked for (RunAheadSink::WantsModels):
+  const float* ind_pred = nullptr;     // [n][2 * n_ind] what the models' blackboard slots held ([2i] indirect, [2i+1] run map)
+  const uint8_t* ind_active = nullptr; // [n][2 * n_ind] whether SetLogitPrediction marked them active
+  int n_ind = 0;
+  const float* lstm_pred = nullptr;    // [n / 8][8] the LSTM's slot, bit by bit
+  const uint8_t* lstm_active = nullptr;
+};
 struct RunAheadSink {
   virtual ~RunAheadSink() {}
-  // n bits of this stream, oldest first: p[i] is what Predictor::Predict() would have returned for bit i,
-  // bits[i] the bit that was then perceived, outputs[i * n_mixers + j] mixer j's output (logit domain).
-  virtual void Drain(const float* p, const uint8_t* bits, const float* outputs, int n_mixers, uint64_t n) = 0;
+  virtual void Drain(const RunAheadView& v) = 0;
+  virtual bool WantsModels() const { return false; }  // also bring the device-side feature models' predictions back
 };
 
-// The mixer banks of up to n_streams Predictors in ONE gmx_group (one stream each), and the two-batch ring
-// their run-ahead chunks travel through.  A bank constructed while a pool is installed takes a stream of it;
-// otherwise every bank owns a pool of one stream, which is the plain drop-in.  The Predictors may live on
-// different threads (one file per thread): every C-ABI call on the shared group happens under the pool's
-// mutex, the chunk of a round is submitted by whichever stream arrives last, and a stream only ever touches
-// its own stretch of the batches' arrays.
+// The device banks of up to n_streams Predictors -- ONE gmx_group, and one gmx_indirect / gmx_lstm where the
+// Predictors' Indirect models / LSTM are on the device as well -- one stream per Predictor, and the rings their
+// run-ahead chunks travel through.  Banks constructed while a pool is installed take a stream of it; otherwise
+// every Predictor owns a pool of one stream, which is the plain drop-in.  The Predictors may live on different
+// threads (one file per thread): every C-ABI call on the shared objects happens under the pool's mutex, the
+// chunk of a round is submitted by whichever stream arrives last, and a stream only ever touches its own
+// stretch of the batches' arrays.
 class MixerPool {
  public:
-  explicit MixerPool(int n_streams, int device = -1) : S_(n_streams < 1 ? 1 : n_streams), device_(device), used_(S_, 0) {
+  explicit MixerPool(int n_streams, int device = -1) : S_(n_streams < 1 ? 1 : n_streams), device_(device), streams_(S_) {
     if (device_ < 0) {
       const char* dev = getenv("GMX_DEVICE");
       device_ = dev ? atoi(dev) : 0;
@@ -128,9 +126,14 @@ class MixerPool {
   }
   ~MixerPool() {
     Uninstall();
-    for (gmx_batch* b : ring_)
-      if (b) gmx_batch_destroy(b);
+    for (int k = 0; k < 2; ++k) {
+      if (ring_[k]) gmx_batch_destroy(ring_[k]);
+      if (iring_[k]) gmx_ind_batch_destroy(iring_[k]);
+      if (lring_[k]) gmx_lstm_batch_destroy(lring_[k]);
+    }
     if (group_) gmx_group_destroy(group_);
+    if (ind_) gmx_indirect_destroy(ind_);
+    if (lstm_) gmx_lstm_destroy(lstm_);
   }
   MixerPool(const MixerPool&) = delete;
   MixerPool& operator=(const MixerPool&) = delete;
@@ -139,6 +142,8 @@ class MixerPool {
     static MixerPool* p = nullptr;
     return p;
   }
+  // From now on the banks of every Predictor constructed (on any thread) live in this pool.  The pool must
+  // outlive them.
   void Install() {
     std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
     Installed() = this;
@@ -151,6 +156,8 @@ class MixerPool {
   int n_streams() const { return S_; }
   int device() const { return device_; }
   gmx_group* group() const { return group_; }
+  gmx_indirect* indirect() const { return ind_; }
+  gmx_lstm* lstm() const { return lstm_; }
   // 0, or the status of the first C-ABI call that failed on this pool (shared pools report instead of aborting)
   int status() const { return status_.load(); }
   std::string error() const {
@@ -158,30 +165,82 @@ class MixerPool {
     return error_;
   }
   uint64_t chunk_bits() const { return T_; }
-  // bits of all streams submitted to the device so far, launches made
-  uint64_t bits_submitted() const { return bits_submitted_; }
-  uint64_t rounds() const { return round_; }
+  uint64_t bits_submitted() const { return bits_submitted_; }  // bits of all streams queued on the device so far
+  uint64_t rounds() const { return round_; }                   // chunks (of all streams together) handed in
+
+  enum Parts { kMixers = 1, kIndirect = 2, kLstm = 4 };
 
  private:
   friend class GpuMixerBank;
-  struct View {  // a stream's stretch of the batch whose results are back
-    const float* p = nullptr;
-    const float* out = nullptr;
-    const uint8_t* bits = nullptr;
-    uint64_t n = 0;
+  friend class GpuIndirectBank;
+  friend class GpuLstmModel;
+
+  struct Stream {  // one Predictor's place in the pool
+    const LongTermMemory* owner = nullptr;
+    int refs = 0;
+    GpuMixerBank* mixers = nullptr;
+    GpuIndirectBank* indirect = nullptr;
+    GpuLstmModel* lstm = nullptr;
+    // run-ahead: where the chunk being filled is recorded, and how many bits of it are
+    bool ra = false;
+    uint64_t t = 0;
+    float* pred = nullptr;
+    uint32_t *mask = nullptr, *ctx = nullptr;
+    uint8_t* bits = nullptr;
+    uint32_t *ictx = nullptr, *ibc = nullptr;
+    uint8_t* ibits = nullptr;
+    float* ppm = nullptr;
+    uint8_t* bytes = nullptr;
   };
-  int Acquire() {
-    std::lock_guard<std::mutex> lk(mu_);
-    for (int i = 0; i < S_; ++i)
-      if (!used_[i]) {
-        used_[i] = 1;
-        return i;
+
+  // The pool and stream of the Predictor that owns `ltm`: the installed pool, else a pool of its own (shared by
+  // the mixers', the Indirect models' and the LSTM's adapters of that Predictor).
+  static std::shared_ptr<MixerPool> Attach(const LongTermMemory* ltm, int* slot) {
+    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
+    std::shared_ptr<MixerPool> sp;
+    auto& priv = Private();
+    auto it = priv.find(ltm);
+    if (it != priv.end()) sp = it->second.lock();
+    if (!sp) {
+      if (MixerPool* inst = Installed()) {
+        sp = std::shared_ptr<MixerPool>(inst, [](MixerPool*) {});
+      } else {
+        sp.reset(new MixerPool(1));
       }
-    return -1;
+      priv[ltm] = sp;
+    }
+    std::lock_guard<std::mutex> lk2(sp->mu_);
+    int free_slot = -1;
+    for (int i = 0; i < sp->S_; ++i) {
+      if (sp->streams_[i].owner == ltm) {
+        ++sp->streams_[i].refs;
+        *slot = i;
+        return sp;
+      }
+      if (!sp->streams_[i].owner && free_slot < 0) free_slot = i;
+    }
+    if (free_slot < 0) {
+      fprintf(stderr, "\ngmx: the installed MixerPool has no free stream (%d in use)\n", sp->S_);
+      abort();
+    }
+    sp->streams_[free_slot] = Stream();
+    sp->streams_[free_slot].owner = ltm;
+    sp->streams_[free_slot].refs = 1;
+    *slot = free_slot;
+    return sp;
   }
-  void Release(int slot) {
-    std::lock_guard<std::mutex> lk(mu_);
-    if (slot >= 0 && slot < S_) used_[slot] = 0;
+  void Detach(int slot) {
+    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
+    std::lock_guard<std::mutex> lk2(mu_);
+    Stream& st = streams_[slot];
+    if (--st.refs <= 0) {
+      Private().erase(st.owner);
+      st = Stream();
+    }
+  }
+  static std::map<const LongTermMemory*, std::weak_ptr<MixerPool>>& Private() {
+    static std::map<const LongTermMemory*, std::weak_ptr<MixerPool>> r;
+    return r;
   }
   int Fail(const char* what, int rc) {  // mu_ held
     if (status_.load() == 0) {
@@ -191,8 +250,32 @@ class MixerPool {
     cv_.notify_all();
     return rc;
   }
-  // The group is made from the first bank's topology (all constructors of its Predictor have run by then);
-  // the other banks must describe the same one.  mu_ held.
+  // A failed call: a pool that hosts many compressors reports (status(), error()); a Predictor's own pool
+  // aborts, the convention of the reference's tester (tester.cpp:318-321).  mu_ NOT held.
+  void Check(const char* who, const char* what, int rc) {
+    if (rc == GMX_OK) return;
+    if (shared_) {
+      std::lock_guard<std::mutex> lk(mu_);
+      Fail(what, rc);
+      return;
+    }
+    fprintf(stderr, "\n%s: %s: %s %s\n(this model runs on an MI355X through libgmxmix.so; there is no CPU fallback)\n", who,
+            what, gmx_strerror(rc), rc == GMX_ERR_HIP ? gmx_last_error() : "");
+    abort();
+  }
+  // a C-ABI call on the pool's (possibly shared) objects
+  template <class F>
+  void Call(const char* who, const char* what, F f) {
+    if (status_.load()) return;
+    int rc;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      rc = f();
+    }
+    Check(who, what, rc);
+  }
+  // The objects are made from the first Predictor's description (all constructors of it have run by then);
+  // the other Predictors must describe the same ones.  mu_ held.
   int EnsureGroup(const gmx_topology& t) {
     if (group_) {
       bool same = t.n_inputs == n_inputs_ && (size_t)t.n_mixers == descs_.size() && (size_t)t.n_skip == skip_.size();
@@ -207,68 +290,137 @@ class MixerPool {
     skip_.assign(t.skip_index, t.skip_index + t.n_skip);
     return gmx_group_create(&group_, &t, S_, device_);
   }
+  int EnsureIndirect(const std::vector<gmx_indirect_desc>& d, const uint8_t* ns, const uint8_t* rm) {
+    if (ind_) {
+      bool same = d.size() == idescs_.size();
+      for (size_t i = 0; same && i < d.size(); ++i)
+        same = d[i].table_size == idescs_[i].table_size && d[i].learning_rate == idescs_[i].learning_rate &&
+               d[i].slot_indirect == idescs_[i].slot_indirect && d[i].slot_run_map == idescs_[i].slot_run_map;
+      return same ? GMX_OK : GMX_ERR_INVALID;
+    }
+    idescs_ = d;
+    return gmx_indirect_create(&ind_, d.data(), (int)d.size(), ns, rm, S_, device_);
+  }
+  int EnsureLstm() { return lstm_ ? GMX_OK : gmx_lstm_create(&lstm_, S_, device_); }
+
   // ---- the ring ----
-  int Join(int slot, uint64_t chunk_bits) {
+  // parts: which banks of the stream's Predictor are on the device (all streams of a pool alike);
+  // lstm_slot / mixer_ctx_col / ind_ctx_col: where the LSTM's prediction and lstm_prediction_context go
+  // (gmx_lstm_feed); models: the sink wants the feature models' predictions back as well
+  int Join(int slot, uint64_t chunk_bits, int parts, int lstm_slot, int mixer_ctx_col, int ind_ctx_col, bool models) {
     std::unique_lock<std::mutex> lk(mu_);
     if (status_.load()) return status_.load();
     if (!ring_[0]) {
-      T_ = chunk_bits < 8 ? 8 : chunk_bits;
+      T_ = chunk_bits < 8 ? 8 : chunk_bits & ~7ull;
+      parts_ = parts;
+      lstm_slot_ = lstm_slot;
+      mixer_ctx_col_ = mixer_ctx_col;
+      ind_ctx_col_ = ind_ctx_col;
+      models_back_ = models;
       for (int k = 0; k < 2; ++k) {
         int rc = gmx_batch_create(&ring_[k], group_, T_, GMX_BATCH_OUTPUTS | GMX_BATCH_MASK);
         if (rc) return Fail("gmx_batch_create", rc);
         if (!gmx_batch_predictions(ring_[k]) || !gmx_batch_active_mask(ring_[k]) || !gmx_batch_contexts(ring_[k]) ||
             !gmx_batch_bits(ring_[k]) || !gmx_batch_p(ring_[k]) || !gmx_batch_outputs(ring_[k]))
           return Fail("gmx_batch (pinned arrays)", GMX_ERR_NOMEM);
+        if (parts_ & kIndirect) {
+          if ((rc = gmx_ind_batch_create(&iring_[k], ind_, T_))) return Fail("gmx_ind_batch_create", rc);
+          if (!gmx_ind_batch_contexts(iring_[k]) || !gmx_ind_batch_bit_contexts(iring_[k]) || !gmx_ind_batch_bits(iring_[k]))
+            return Fail("gmx_ind_batch (pinned arrays)", GMX_ERR_NOMEM);
+        }
+        if (parts_ & kLstm) {
+          if ((rc = gmx_lstm_batch_create(&lring_[k], lstm_, T_ / 8))) return Fail("gmx_lstm_batch_create", rc);
+          if (!gmx_lstm_batch_ppm(lring_[k]) || !gmx_lstm_batch_bytes(lring_[k]))
+            return Fail("gmx_lstm_batch (pinned arrays)", GMX_ERR_NOMEM);
+        }
       }
       n_pad_ = gmx_batch_n_pad(ring_[0]);
       mask_words_ = gmx_batch_mask_words(ring_[0]);
       M_ = gmx_group_n_mixers(group_);
+      K_ = (parts_ & kIndirect) ? gmx_indirect_n_models(ind_) : 0;
       n_cur_.assign(S_, 0);
       n_in_[0].assign(S_, 0);
       n_in_[1].assign(S_, 0);
+      n_bytes_.assign(S_, 0);
+    } else if (parts != parts_ || lstm_slot != lstm_slot_ || mixer_ctx_col != mixer_ctx_col_ || ind_ctx_col != ind_ctx_col_) {
+      return GMX_ERR_INVALID;  // Predictors of different make in one pool
     }
+    models_back_ = models_back_ || models;
     n_cur_[slot] = 0;
     n_in_[0][slot] = n_in_[1][slot] = 0;
+    streams_[slot].ra = true;
+    streams_[slot].t = 0;
+    Records(slot);
     ++participants_;
     return GMX_OK;
   }
-  // where `slot` records the chunk it is filling
-  void Records(int slot, float** pred, uint32_t** mask, uint32_t** ctx, uint8_t** bits) {
-    std::lock_guard<std::mutex> lk(mu_);
+  // where `slot` records the chunk it is filling.  mu_ held.
+  void Records(int slot) {
+    Stream& st = streams_[slot];
     gmx_batch* b = ring_[cur_];
-    *pred = gmx_batch_predictions(b) + (size_t)slot * T_ * n_pad_;
-    *mask = gmx_batch_active_mask(b) + (size_t)slot * T_ * mask_words_;
-    *ctx = gmx_batch_contexts(b) + (size_t)slot * T_ * M_;
-    *bits = gmx_batch_bits(b) + (size_t)slot * T_;
+    st.pred = gmx_batch_predictions(b) + (size_t)slot * T_ * n_pad_;
+    st.mask = gmx_batch_active_mask(b) + (size_t)slot * T_ * mask_words_;
+    st.ctx = gmx_batch_contexts(b) + (size_t)slot * T_ * M_;
+    st.bits = gmx_batch_bits(b) + (size_t)slot * T_;
+    if (parts_ & kIndirect) {
+      st.ictx = gmx_ind_batch_contexts(iring_[cur_]) + (size_t)slot * T_ * K_;
+      st.ibc = gmx_ind_batch_bit_contexts(iring_[cur_]) + (size_t)slot * T_;
+      st.ibits = gmx_ind_batch_bits(iring_[cur_]) + (size_t)slot * T_;
+    }
+    if (parts_ & kLstm) {
+      st.ppm = gmx_lstm_batch_ppm(lring_[cur_]) + (size_t)slot * (T_ / 8) * 256;
+      st.bytes = gmx_lstm_batch_bytes(lring_[cur_]) + (size_t)slot * (T_ / 8);
+    }
   }
   // Every stream has handed in its chunk: queue it behind the chunk before, wait for THAT one.  mu_ held.
   void Lead() {
-    gmx_batch* b = ring_[cur_];
+    const int c = cur_;
     uint64_t maxn = 0, sum = 0;
     for (int i = 0; i < S_; ++i) {
       maxn = std::max(maxn, n_cur_[i]);
       sum += n_cur_[i];
+      n_bytes_[i] = n_cur_[i] / 8;
     }
     int rc = GMX_OK;
+    const char* what = "";
+#define GMX_POOL_STEP(call)              \
+  if (rc == GMX_OK && (rc = (call))) what = #call
     if (maxn > 0) {
-      if ((rc = gmx_batch_upload(b, maxn))) {
-        Fail("gmx_batch_upload", rc);
-      } else if ((rc = gmx_group_run_ragged(group_, b, n_cur_.data(), 1))) {
-        Fail("gmx_group_run_ragged", rc);
-      } else if ((rc = gmx_batch_download(b, maxn))) {
-        Fail("gmx_batch_download", rc);
-      } else {
-        busy_[cur_] = true;
+      if (parts_ & kLstm) {
+        // LstmModel::Predict x 8 / Learn for every byte of the chunk, then its prediction into the mixers' records
+        // (slot, active flag) and lstm_prediction_context into the gate context / Indirect context that read it
+        GMX_POOL_STEP(gmx_lstm_batch_upload(lring_[c], maxn / 8));
+        GMX_POOL_STEP(gmx_lstm_run_ragged(lstm_, lring_[c], n_bytes_.data(), 1));
+      }
+      if (parts_ & kIndirect) GMX_POOL_STEP(gmx_ind_batch_upload(iring_[c], maxn));
+      GMX_POOL_STEP(gmx_batch_upload(ring_[c], maxn));
+      if (parts_ & kLstm) {
+        GMX_POOL_STEP(gmx_lstm_feed(lstm_, lring_[c], maxn / 8, ring_[c], lstm_slot_, mixer_ctx_col_,
+                                    (parts_ & kIndirect) && ind_ctx_col_ >= 0 ? iring_[c] : nullptr, ind_ctx_col_));
+        if (models_back_) GMX_POOL_STEP(gmx_lstm_batch_download(lring_[c], maxn / 8));
+      }
+      if (parts_ & kIndirect) {
+        GMX_POOL_STEP(gmx_indirect_run_ragged(ind_, iring_[c], n_cur_.data(), 1, ring_[c]));
+        if (models_back_) GMX_POOL_STEP(gmx_ind_batch_download(iring_[c], maxn));
+      }
+      GMX_POOL_STEP(gmx_group_run_ragged(group_, ring_[c], n_cur_.data(), 1));
+      GMX_POOL_STEP(gmx_batch_download(ring_[c], maxn));
+      if (rc == GMX_OK) {
+        busy_[c] = true;
         bits_submitted_ += sum;
       }
     }
-    n_in_[cur_] = n_cur_;
+    n_in_[c] = n_cur_;
     std::fill(n_cur_.begin(), n_cur_.end(), 0);
-    const int other = cur_ ^ 1;
+    const int other = c ^ 1;
     if (rc == GMX_OK && busy_[other]) {
       busy_[other] = false;
-      if ((rc = gmx_batch_wait(ring_[other]))) Fail("gmx_batch_wait", rc);
+      GMX_POOL_STEP(gmx_batch_wait(ring_[other]));
+      if (models_back_ && (parts_ & kIndirect)) GMX_POOL_STEP(gmx_ind_batch_wait(iring_[other]));
+      if (models_back_ && (parts_ & kLstm)) GMX_POOL_STEP(gmx_lstm_batch_wait(lring_[other]));
     }
+#undef GMX_POOL_STEP
+    if (rc) Fail(what, rc);
     cur_ = other;
     arrived_ = 0;
     ++round_;
@@ -276,9 +428,10 @@ class MixerPool {
   }
   // `slot` has recorded n bits into the chunk being filled.  Returns when that chunk is queued on the device
   // and the chunk before it is back: *v is the stream's stretch of THAT one (the arrays it fills next).
-  int Arrive(int slot, uint64_t n, View* v) {
+  int Arrive(int slot, uint64_t n, RunAheadView* v) {
     std::unique_lock<std::mutex> lk(mu_);
     if (status_.load()) return status_.load();
+    if ((parts_ & kLstm) && (n & 7)) return GMX_ERR_STATE;  // the LSTM's records are bytes
     n_cur_[slot] = n;
     const uint64_t my_round = round_;
     if (++arrived_ >= participants_)
@@ -287,15 +440,28 @@ class MixerPool {
       cv_.wait(lk, [&] { return round_ != my_round || status_.load() != 0; });
     if (status_.load()) return status_.load();
     gmx_batch* b = ring_[cur_];
-    v->p = gmx_batch_p(b) + (size_t)slot * T_;
-    v->out = gmx_batch_outputs(b) + (size_t)slot * T_ * M_;
-    v->bits = gmx_batch_bits(b) + (size_t)slot * T_;
     v->n = n_in_[cur_][slot];
+    v->p = gmx_batch_p(b) + (size_t)slot * T_;
+    v->outputs = gmx_batch_outputs(b) + (size_t)slot * T_ * M_;
+    v->n_mixers = M_;
+    v->bits = gmx_batch_bits(b) + (size_t)slot * T_;
+    if (models_back_ && (parts_ & kIndirect)) {
+      v->ind_pred = gmx_ind_batch_predictions(iring_[cur_]) + (size_t)slot * T_ * 2 * K_;
+      v->ind_active = gmx_ind_batch_active(iring_[cur_]) + (size_t)slot * T_ * 2 * K_;
+      v->n_ind = K_;
+    }
+    if (models_back_ && (parts_ & kLstm)) {
+      v->lstm_pred = gmx_lstm_batch_predictions(lring_[cur_]) + (size_t)slot * (T_ / 8) * 8;
+      v->lstm_active = gmx_lstm_batch_active(lring_[cur_]) + (size_t)slot * (T_ / 8) * 8;
+    }
     n_in_[cur_][slot] = 0;
+    streams_[slot].t = 0;
+    Records(slot);
     return GMX_OK;
   }
   void Leave(int slot) {
     std::unique_lock<std::mutex> lk(mu_);
+    streams_[slot].ra = false;
     if (participants_ > 0) --participants_;
     if (!n_cur_.empty()) n_cur_[slot] = 0;
     if (participants_ > 0 && arrived_ >= participants_ && status_.load() == 0) Lead();
@@ -305,24 +471,30 @@ class MixerPool {
   int device_;
   bool shared_ = false;
   gmx_group* group_ = nullptr;
+  gmx_indirect* ind_ = nullptr;
+  gmx_lstm* lstm_ = nullptr;
   int n_inputs_ = 0;
   std::vector<gmx_mixer_desc> descs_;
   std::vector<int32_t> skip_;
-  std::vector<char> used_;
+  std::vector<gmx_indirect_desc> idescs_;
+  std::vector<Stream> streams_;
   mutable std::mutex mu_;
   std::condition_variable cv_;
   std::atomic<int> status_{0};
   std::string error_;
   gmx_batch* ring_[2] = {nullptr, nullptr};
+  gmx_ind_batch* iring_[2] = {nullptr, nullptr};
+  gmx_lstm_batch* lring_[2] = {nullptr, nullptr};
   bool busy_[2] = {false, false};
-  int cur_ = 0;
+  int cur_ = 0, parts_ = 0, lstm_slot_ = -1, mixer_ctx_col_ = -1, ind_ctx_col_ = -1;
+  bool models_back_ = false;
   uint64_t T_ = 0, round_ = 0, bits_submitted_ = 0;
-  int n_pad_ = 0, mask_words_ = 0, M_ = 0;
+  int n_pad_ = 0, mask_words_ = 0, M_ = 0, K_ = 0;
   int participants_ = 0, arrived_ = 0;
-  std::vector<uint64_t> n_cur_, n_in_[2];
+  std::vector<uint64_t> n_cur_, n_in_[2], n_bytes_;
 };
 
-// All mixers of one Predictor: one stream of a gmx_group (its own, or a MixerPool's).
+// All mixers of one Predictor: one stream of a gmx_group (the Predictor's own, or a MixerPool's).
 class GpuMixerBank {
  public:
   // The bank of the Predictor that owns `ltm` (created on first use, gone with its last mixer).
@@ -348,83 +520,48 @@ class GpuMixerBank {
     return nullptr;
   }
   ~GpuMixerBank() {
-    if (ra_) {
-      pool_->Leave(slot_);
-      ra_ = false;
+    if (st().ra) pool_->Leave(slot_);
+    {
+      std::lock_guard<std::mutex> lk(pool_->mu_);
+      st().mixers = nullptr;
     }
-    pool_->Release(slot_);
+    pool_->Detach(slot_);
     std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
     Registry().erase(&ltm_);
-    ChainConsumers().erase(&ltm_);
   }
   GpuMixerBank(const GpuMixerBank&) = delete;
   GpuMixerBank& operator=(const GpuMixerBank&) = delete;
 
   gmx_group* group() { return group_; }
   int stream() const { return slot_; }
-  MixerPool* pool() { return pool_; }
+  MixerPool* pool() { return pool_.get(); }
   ShortTermMemory& stm() { return stm_; }
   LongTermMemory& ltm() { return ltm_; }
   int n_mixers() const { return (int)descs_.size(); }
-  bool running_ahead() const { return ra_; }
-  // 0, or the status of the C-ABI call that failed (a bank of a shared pool reports; a bank of its own aborts,
-  // the convention of the reference's tester, tester.cpp:318-321)
+  bool running_ahead() const { return pool_->streams_[slot_].ra; }
+  // 0, or the status of the C-ABI call that failed (a bank of a shared pool reports; a bank of its own aborts)
   int status() const { return pool_->status(); }
+  // the device-side feature models of this Predictor, for whoever interprets a RunAheadView:
+  // prediction slots of Indirect model i ([2i] indirect, [2i+1] run map), the LSTM's slot (-1: on the host)
+  std::vector<int> IndirectSlots() const;
+  int LstmSlot() const;
 
-  // From the next Predict on the mixers record instead of compute; results reach `sink` one chunk later.
-  // Every bit must be Predict -> Perceive -> Learn (the path that knows its bits: runner-utils.cpp:43-67, :223-322).
-  int BeginRunAhead(RunAheadSink* sink, uint64_t chunk_bits) {
-    if (ra_) return GMX_ERR_STATE;
-    Settle();
-    if (status()) return status();
-    // rows this bank has seen (Mixer::contexts_seen_ / GetMemoryUsage while the device runs behind)
-    seen_.assign(descs_.size(), std::vector<uint64_t>());
-    seen_count_.assign(descs_.size(), 0);
-    for (size_t j = 0; j < descs_.size(); ++j) seen_[j].assign(((size_t)descs_[j].table_size + 63) / 64, 0);
-    bool fresh = true;
-    for (size_t j = 0; j < descs_.size(); ++j) {
-      uint64_t sh[3];
-      memcpy(sh, &short_cache_[24 * j], 24);
-      fresh = fresh && sh[0] == 0;
-    }
-    if (!fresh || ever_ran_) {
-      Stage();
-      for (size_t j = 0; j < descs_.size(); ++j) {
-        auto& table = ltm_.mixers[memory_index_[j]].mixer_table;
-        for (size_t c = 0; c < table.size(); ++c)
-          if (table[c]) {
-            seen_[j][c >> 6] |= 1ull << (c & 63);
-            ++seen_count_[j];
-          }
-      }
-      Unstage();
-    }
-    int rc = pool_->Join(slot_, chunk_bits);
-    if (rc) return rc;
-    T_ = pool_->chunk_bits();
-    n_pad_ = pool_->n_pad_;
-    mask_words_ = pool_->mask_words_;
-    pool_->Records(slot_, &ra_pred_, &ra_mask_, &ra_ctx_, &ra_bits_);
-    t_ = 0;
-    recorded_ = false;
-    sink_ = sink;
-    ra_ = true;
-    ever_ran_ = true;
-    return GMX_OK;
-  }
+  // From the next Predict on, the device-side models record instead of compute; results reach `sink` one chunk
+  // later.  Every bit must be Predict -> Perceive -> Learn (the paths that know their bits:
+  // runner-utils.cpp:43-67, :223-322); with the LSTM on the device, start and end on byte boundaries.
+  int BeginRunAhead(RunAheadSink* sink, uint64_t chunk_bits);
   // Hands in what is recorded, brings every outstanding result home (through the sink) and leaves the
   // blackboard's mixer outputs as per-bit calls would have.
   int EndRunAhead() {
-    if (!ra_) return GMX_OK;
+    if (!st().ra) return GMX_OK;
     int rc = SyncRunAhead();
     pool_->Leave(slot_);
-    ra_ = false;
     sink_ = nullptr;
     return rc;
   }
   // The same without leaving run-ahead mode (a checkpoint in the middle of a file).
   int SyncRunAhead() {
-    if (!ra_) return GMX_OK;
+    if (!st().ra) return GMX_OK;
     int rc = Flush();
     if (rc == GMX_OK) rc = Flush();
     return rc;
@@ -432,45 +569,22 @@ class GpuMixerBank {
 
  private:
   friend class GpuMixer;
+  friend class GpuIndirectBank;
+  friend class GpuLstmModel;
   GpuMixerBank(ShortTermMemory& stm, LongTermMemory& ltm) : stm_(stm), ltm_(ltm) {
-    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
-    pool_ = MixerPool::Installed();
-    if (!pool_) {
-      own_pool_.reset(new MixerPool(1));
-      pool_ = own_pool_.get();
-      ChainConsumers()[&ltm] = 1;  // (gmx_chain_forward pairs stream 0 of the two banks: banks of their own only)
-    }
-    slot_ = pool_->Acquire();
-    if (slot_ < 0) {
-      fprintf(stderr, "\ngmx::GpuMixer: the installed MixerPool has no free stream (%d in use)\n", pool_->n_streams());
-      abort();
-    }
+    pool_ = MixerPool::Attach(&ltm, &slot_);
+    std::lock_guard<std::mutex> lk(pool_->mu_);
+    st().mixers = this;
   }
   static std::map<const LongTermMemory*, std::weak_ptr<GpuMixerBank>>& Registry() {
     static std::map<const LongTermMemory*, std::weak_ptr<GpuMixerBank>> r;
     return r;
   }
-  void Check(const char* what, int rc) {
-    if (rc == GMX_OK) return;
-    if (pool_->shared_) {  // a process that hosts many compressors: report, do not take it down
-      std::lock_guard<std::mutex> lk(pool_->mu_);
-      pool_->Fail(what, rc);
-      return;
-    }
-    fprintf(stderr, "\ngmx::GpuMixer: %s: %s %s\n(the mixers run on an MI355X through libgmxmix.so; there is no CPU fallback)\n",
-            what, gmx_strerror(rc), rc == GMX_ERR_HIP ? gmx_last_error() : "");
-    abort();
-  }
-  // a C-ABI call on the (possibly shared) group
+  MixerPool::Stream& st() { return pool_->streams_[slot_]; }
+  void Check(const char* what, int rc) { pool_->Check("gmx::GpuMixer", what, rc); }
   template <class F>
   void Call(const char* what, F f) {
-    if (pool_->status()) return;
-    int rc;
-    {
-      std::lock_guard<std::mutex> lk(pool_->mu_);
-      rc = f();
-    }
-    Check(what, rc);
+    pool_->Call("gmx::GpuMixer", what, f);
   }
   int Register(GpuMixer* m, int layer, unsigned table_size, float lr, int memory_index, int weight_size) {
     gmx_mixer_desc d;
@@ -510,7 +624,7 @@ class GpuMixerBank {
   void Settle() {
     Ensure();
     if (!import_pending_) return;
-    if (ra_) SyncRunAhead();
+    if (st().ra) SyncRunAhead();
     import_pending_ = false;
     std::vector<char> buf;
     auto put = [&buf](const void* p, size_t n) {
@@ -543,7 +657,7 @@ class GpuMixerBank {
   // Bank -> LongTermMemory::mixers (+ the 3 x u64 of every mixer), for the reference's writers.
   void Stage() {
     Settle();
-    if (ra_) SyncRunAhead();
+    if (st().ra) SyncRunAhead();
     size_t nl = 0, ns = 0;
     Call("gmx_bank_export", [&] { return gmx_bank_export(group_, slot_, nullptr, &nl, nullptr, &ns); });
     std::vector<char> l(nl ? nl : 1);
@@ -579,32 +693,36 @@ class GpuMixerBank {
       for (auto& row : ltm_.mixers[memory_index_[j]].mixer_table) row.reset();
   }
   void PredictAll(ShortTermMemory& stm);
-  void ToBlackboard(ShortTermMemory& stm);
   void LearnAll(const ShortTermMemory& stm) {
     Settle();
-    if (ra_) {
+    MixerPool::Stream& s = st();
+    if (s.ra) {
       if (!recorded_ || status()) return;  // (a Learn without its Predict has nothing to learn from)
       recorded_ = false;
-      ra_bits_[t_] = (uint8_t)stm.new_bit;
-      const uint32_t* c = ra_ctx_ + (size_t)t_ * descs_.size();
+      s.bits[s.t] = (uint8_t)stm.new_bit;
+      const uint32_t* c = s.ctx + (size_t)s.t * descs_.size();
       for (size_t j = 0; j < descs_.size(); ++j) {  // Mixer::FindOrCreateMixerData's ++contexts_seen_ (mixer.cpp:39-49)
-        const uint32_t row = c[j] % descs_[j].table_size;
-        uint64_t& w = seen_[j][row >> 6];
-        const uint64_t bit = 1ull << (row & 63);
-        if (!(w & bit)) {
-          w |= bit;
-          ++seen_count_[j];
-        }
+        if ((int)j == lstm_ctx_col_) continue;      // (that context is the device's: counted when its chunk returns)
+        MarkSeen(j, c[j]);
       }
-      if (++t_ == T_) Flush();
+      if (++s.t == T_) Flush();
       return;
     }
     ever_ran_ = true;
     Call("gmx_bank_learn", [&] { return gmx_bank_learn(group_, slot_, stm.new_bit); });
   }
+  void MarkSeen(size_t j, uint32_t context) {
+    const uint32_t row = context % descs_[j].table_size;
+    uint64_t& w = seen_[j][row >> 6];
+    const uint64_t bit = 1ull << (row & 63);
+    if (!(w & bit)) {
+      w |= bit;
+      ++seen_count_[j];
+    }
+  }
   void CopyFrom(GpuMixerBank& o) {
-    if (o.ra_) o.SyncRunAhead();
-    if (ra_) SyncRunAhead();
+    if (o.st().ra) o.SyncRunAhead();
+    if (st().ra) SyncRunAhead();
     o.Settle();
     Ensure();
     import_pending_ = false;  // whatever LongTermMemory::Copy moves into the staging area is not ours to import
@@ -612,8 +730,8 @@ class GpuMixerBank {
     if (o.pool_ == pool_) {
       Call("gmx_bank_copy", [&] { return gmx_bank_copy(group_, slot_, o.group_, o.slot_); });
     } else {  // two groups: both pools' calls held off, always in address order
-      MixerPool* a = pool_ < o.pool_ ? pool_ : o.pool_;
-      MixerPool* b = pool_ < o.pool_ ? o.pool_ : pool_;
+      MixerPool* a = pool_.get() < o.pool_.get() ? pool_.get() : o.pool_.get();
+      MixerPool* b = pool_.get() < o.pool_.get() ? o.pool_.get() : pool_.get();
       int rc;
       {
         std::lock_guard<std::mutex> la(a->mu_);
@@ -622,14 +740,14 @@ class GpuMixerBank {
       }
       Check("gmx_bank_copy", rc);
     }
-    if (ra_) {  // the copied bank's rows are this bank's now
-      seen_ = o.seen_.empty() ? seen_ : o.seen_;
-      seen_count_ = o.seen_count_.empty() ? seen_count_ : o.seen_count_;
+    if (st().ra && !o.seen_.empty()) {  // the copied bank's rows are this bank's now
+      seen_ = o.seen_;
+      seen_count_ = o.seen_count_;
     }
   }
   unsigned long long MemoryUsage(int index) {
     Settle();
-    if (ra_)  // mixer.cpp:197-205 from the host's own count of rows (the device runs a chunk behind)
+    if (st().ra)  // mixer.cpp:197-205 from the host's own count of rows (the device runs a chunk behind)
       return 29ull + seen_count_[index] * (unsigned long long)(weight_size_[index] * 4 + 12) +
              8ull * descs_[index].table_size;
     uint64_t v = 0;
@@ -637,29 +755,11 @@ class GpuMixerBank {
     return v;
   }
   // One round of the ring: the chunk recorded so far goes to the device, the chunk before it comes back.
-  int Flush() {
-    MixerPool::View v;
-    int rc = pool_->Arrive(slot_, t_, &v);
-    t_ = 0;
-    if (rc) return rc;
-    if (v.n) {
-      const int M = (int)descs_.size();
-      if (sink_) sink_->Drain(v.p, v.bits, v.out, M, v.n);
-      // mixer.cpp:99-105: where the Mixer::Predict calls of the newest bit left their results
-      const float* o = v.out + (size_t)(v.n - 1) * M;
-      size_t j = 0;
-      for (int k = 0; k < stm_.num_layer0_mixers; ++k) stm_.mixer_layer0_outputs[k] = o[j++];
-      for (int k = 0; k < stm_.num_layer1_mixers; ++k) stm_.mixer_layer1_outputs[k] = o[j++];
-      if (j < (size_t)M) stm_.final_mixer_output = o[j];
-    }
-    pool_->Records(slot_, &ra_pred_, &ra_mask_, &ra_ctx_, &ra_bits_);
-    return GMX_OK;
-  }
+  int Flush();
 
   ShortTermMemory& stm_;
   LongTermMemory& ltm_;
-  std::unique_ptr<MixerPool> own_pool_;
-  MixerPool* pool_ = nullptr;
+  std::shared_ptr<MixerPool> pool_;
   int slot_ = 0;
   gmx_group* group_ = nullptr;
   std::vector<gmx_mixer_desc> descs_;
@@ -672,14 +772,10 @@ class GpuMixerBank {
   std::vector<char> short_cache_, short_in_;
   bool import_pending_ = false, staged_ = false, ever_ran_ = false;
   // run-ahead
-  bool ra_ = false, recorded_ = false;
+  bool recorded_ = false;
   RunAheadSink* sink_ = nullptr;
-  uint64_t T_ = 0, t_ = 0;
-  int n_pad_ = 0, mask_words_ = 0;
-  float* ra_pred_ = nullptr;
-  uint32_t* ra_mask_ = nullptr;
-  uint32_t* ra_ctx_ = nullptr;
-  uint8_t* ra_bits_ = nullptr;
+  uint64_t T_ = 0;
+  int n_pad_ = 0, mask_words_ = 0, lstm_ctx_col_ = -1;
   std::vector<std::vector<uint64_t>> seen_;
   std::vector<uint64_t> seen_count_;
 };
@@ -735,64 +831,13 @@ class GpuMixer : public Model {
     return bank_->MemoryUsage(index_);
   }
   unsigned int context() const { return context_; }
+  const unsigned int* context_address() const { return &context_; }
 
  private:
   unsigned int& context_;  // aliases a field of the Predictor's blackboard (mixer.h:31)
   std::shared_ptr<GpuMixerBank> bank_;
   int index_;  // construction order within the bank
 };
-
-inline void GpuMixerBank::PredictAll(ShortTermMemory& stm) {
-  Settle();
-  if (status()) return;
-  if (ra_) {
-    // Mixer::Predict x 33, recorded: the raw blackboard, active_models as a mask, the contexts read now
-    if (recorded_) {  // a Predict whose bit was never learned: not a path that runs ahead
-      Check("run-ahead needs Predict -> Perceive -> Learn for every bit", GMX_ERR_STATE);
-      return;
-    }
-    const int N = stm.num_predictions;
-    memcpy(ra_pred_ + (size_t)t_ * n_pad_, &stm.predictions[0], 4 * (size_t)N);
-    uint32_t* m = ra_mask_ + (size_t)t_ * mask_words_;
-    for (int w = 0; w < mask_words_; ++w) m[w] = 0;
-    for (int idx : stm.active_models) m[idx >> 5] |= 1u << (idx & 31);
-    uint32_t* c = ra_ctx_ + (size_t)t_ * mixers_.size();
-    for (size_t j = 0; j < mixers_.size(); ++j) c[j] = mixers_[j]->context();
-    recorded_ = true;
-    return;
-  }
-  for (size_t j = 0; j < mixers_.size(); ++j) contexts_[j] = mixers_[j]->context();  // read at call time
-  static_assert(sizeof(int) == sizeof(int32_t), "active_models is passed as it stands");
-  float p = 0.5f;
-  ChainProducer* ind = nullptr;
-  {
-    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
-    auto it = ChainProducers().find(&ltm_);
-    if (it != ChainProducers().end() && it->second->Pending()) ind = it->second;
-  }
-  ever_ran_ = true;
-  if (ind) {
-    // the Indirect models' Predict of this bit is still to run: both banks in one round trip
-    chain_pred_.resize(128);  // two slots for each of at most 64 models (gmx_indirect_create's limit)
-    chain_act_.resize(128);
-    Call("gmx_chain_forward", [&] {
-      return gmx_chain_forward(ind->Handle(), group_, slot_, ind->Contexts(), ind->BitContext(), &stm.predictions[0],
-                               stm.active_models.data(), (int)stm.active_models.size(), contexts_.data(), &p,
-                               outputs_.data(), chain_pred_.data(), chain_act_.data());
-    });
-    ind->Deliver(stm, chain_pred_.data(), chain_act_.data());
-  } else {
-    Call("gmx_bank_forward", [&] {
-      return gmx_bank_forward(group_, slot_, &stm.predictions[0], stm.active_models.data(),
-                              (int)stm.active_models.size(), contexts_.data(), &p, outputs_.data());
-    });
-  }
-  // mixer.cpp:99-105: where each Mixer::Predict leaves its result
-  size_t j = 0;
-  for (int k = 0; k < stm.num_layer0_mixers; ++k) stm.mixer_layer0_outputs[k] = outputs_[j++];
-  for (int k = 0; k < stm.num_layer1_mixers; ++k) stm.mixer_layer1_outputs[k] = outputs_[j++];
-  if (j < outputs_.size()) stm.final_mixer_output = outputs_[j];
-}
 
 // ================================================================================================
 // The same for the two feature models that live on the device next to the mixers (SURVEY.md
@@ -804,10 +849,11 @@ inline void GpuMixerBank::PredictAll(ShortTermMemory& stm) {
 // reference's own host code (oracle/ref_build builds it as gmix_chain / ref_tester_chain).
 // ================================================================================================
 
-class GpuIndirect;
-
-// All Indirect models of one Predictor: one gmx_indirect with one stream.
-class GpuIndirectBank : public ChainProducer {
+// All Indirect models of one Predictor: one stream of a gmx_indirect.  The last feature model in front of the
+// mixers is an Indirect model (predictor.cpp:24-28), so per bit its bank does not run at its own Predict but
+// hands contexts to the first mixer's: gmx_chain_forward then takes both banks through ONE host round trip (the
+// Indirect wave rings the mixers' wave itself).  GMX_CHAIN_FUSED=0 switches back to one call per bank.
+class GpuIndirectBank {
  public:
   static std::shared_ptr<GpuIndirectBank> For(ShortTermMemory& stm, LongTermMemory& ltm) {
     std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
@@ -820,40 +866,33 @@ class GpuIndirectBank : public ChainProducer {
     return sp;
   }
   ~GpuIndirectBank() {
-    if (h_) gmx_indirect_destroy(h_);
+    {
+      std::lock_guard<std::mutex> lk(pool_->mu_);
+      st().indirect = nullptr;
+    }
+    pool_->Detach(slot_);
     std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
     Registry().erase(&ltm_);
-    ChainProducers().erase(&ltm_);
-  }
-  // ChainProducer
-  bool Pending() const override { return pending_; }
-  gmx_indirect* Handle() override { return h_; }
-  const uint32_t* Contexts() const override { return contexts_.data(); }
-  uint32_t BitContext() const override { return pending_bit_context_; }
-  void Deliver(ShortTermMemory& stm, const float* pred, const uint8_t* active) override {
-    pending_ = false;
-    std::copy(pred, pred + pred_.size(), pred_.begin());
-    std::copy(active, active + active_.size(), active_.begin());
-    ToBlackboard(stm);
   }
   GpuIndirectBank(const GpuIndirectBank&) = delete;
   GpuIndirectBank& operator=(const GpuIndirectBank&) = delete;
 
  private:
   friend class GpuIndirect;
+  friend class GpuMixerBank;
   GpuIndirectBank(ShortTermMemory& stm, LongTermMemory& ltm) : stm_(stm), ltm_(ltm) {
-    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
-    ChainProducers()[&ltm] = this;
+    pool_ = MixerPool::Attach(&ltm, &slot_);
+    std::lock_guard<std::mutex> lk(pool_->mu_);
+    st().indirect = this;
   }
   static std::map<const LongTermMemory*, std::weak_ptr<GpuIndirectBank>>& Registry() {
     static std::map<const LongTermMemory*, std::weak_ptr<GpuIndirectBank>> r;
     return r;
   }
-  static void Check(const char* what, int rc) {
-    if (rc == GMX_OK) return;
-    fprintf(stderr, "\ngmx::GpuIndirect: %s: %s %s\n(the Indirect models run on an MI355X through libgmxmix.so; there is no CPU fallback)\n",
-            what, gmx_strerror(rc), rc == GMX_ERR_HIP ? gmx_last_error() : "");
-    abort();
+  MixerPool::Stream& st() { return pool_->streams_[slot_]; }
+  template <class F>
+  void Call(const char* what, F f) {
+    pool_->Call("gmx::GpuIndirect", what, f);
   }
   int Register(GpuIndirect* m, unsigned table_size, float lr, int slot_a, int slot_b, int memory_index) {
     gmx_indirect_desc d;
@@ -876,12 +915,27 @@ class GpuIndirectBank : public ChainProducer {
         ns[2 * s + b] = (uint8_t)stm_.nonstationary.Next(s, b);
         rm[2 * s + b] = (uint8_t)stm_.run_map.Next(s, b);
       }
-    const char* dev = getenv("GMX_DEVICE");
-    Check("gmx_indirect_create",
-          gmx_indirect_create(&h_, descs_.data(), (int)descs_.size(), ns, rm, 1, dev ? atoi(dev) : 0));
+    Call("gmx_indirect_create", [&] { return pool_->EnsureIndirect(descs_, ns, rm); });
+    h_ = pool_->indirect();
     contexts_.assign(descs_.size(), 0u);
     pred_.assign(2 * descs_.size(), 0.f);
     active_.assign(2 * descs_.size(), 0);
+  }
+  // LongTermMemory::indirect is only the staging area of the reference's serialisers here: its tables (790 MB for
+  // the stock models) exist while a checkpoint is being written or read, and not otherwise.
+  void StagingTables(bool on) {
+    for (size_t i = 0; i < descs_.size(); ++i) {
+      auto& mem = ltm_.indirect[memory_index_[i]];
+      if (on) {
+        const size_t size = (size_t)descs_[i].table_size * 256 + 1;  // indirect.cpp:14-19
+        mem.nonstationary_table.assign(size, 255);
+        mem.run_map_table.assign(size, 0);
+      } else {
+        std::vector<unsigned char>().swap(mem.nonstationary_table);
+        std::vector<unsigned char>().swap(mem.run_map_table);
+      }
+    }
+    tables_staged_ = on;
   }
   // Tables the reference's LongTermMemory::ReadFromDisk has read since ReadFromDisk was called on the
   // models go to the device (the indirect section's own format, long-term-memory.cpp:8-32).
@@ -914,15 +968,18 @@ class GpuIndirectBank : public ChainProducer {
       put(mem.nonstationary_predictions.data(), 256 * 4);
       put(mem.run_map_predictions.data(), 256 * 4);
     }
-    Check("gmx_indirect_import", gmx_indirect_import(h_, 0, buf.data(), buf.size()));
+    Call("gmx_indirect_import", [&] { return gmx_indirect_import(h_, slot_, buf.data(), buf.size()); });
+    StagingTables(false);
   }
   // Device -> LongTermMemory::indirect, for the reference's writer.
   void Stage() {
     Settle();
     size_t n = 0;
-    Check("gmx_indirect_export", gmx_indirect_export(h_, 0, nullptr, &n));
+    Call("gmx_indirect_export", [&] { return gmx_indirect_export(h_, slot_, nullptr, &n); });
     std::vector<char> buf(n ? n : 1);
-    Check("gmx_indirect_export", gmx_indirect_export(h_, 0, buf.data(), &n));
+    Call("gmx_indirect_export", [&] { return gmx_indirect_export(h_, slot_, buf.data(), &n); });
+    if (pool_->status()) return;
+    StagingTables(true);
     const char* p = buf.data();
     for (size_t i = 0; i < descs_.size(); ++i) {
       auto& mem = ltm_.indirect[memory_index_[i]];
@@ -931,8 +988,6 @@ class GpuIndirectBank : public ChainProducer {
       memcpy(&count, p, 4);
       p += 4;
       if (count < size / 3) {
-        std::fill(mem.nonstationary_table.begin(), mem.nonstationary_table.end(), (unsigned char)255);
-        std::fill(mem.run_map_table.begin(), mem.run_map_table.end(), (unsigned char)0);
         for (unsigned int k = 0; k < count; ++k) {
           unsigned int key;
           memcpy(&key, p, 4);
@@ -950,21 +1005,33 @@ class GpuIndirectBank : public ChainProducer {
       p += 2048;
     }
   }
+  void Unstage() {
+    if (tables_staged_ && !import_pending_) StagingTables(false);
+  }
   void PredictAll(ShortTermMemory& stm);
   void ToBlackboard(ShortTermMemory& stm);
+  void Deliver(ShortTermMemory& stm, const float* pred, const uint8_t* active) {  // from gmx_chain_forward
+    pending_ = false;
+    std::copy(pred, pred + pred_.size(), pred_.begin());
+    std::copy(active, active + active_.size(), active_.begin());
+    ToBlackboard(stm);
+  }
   void LearnAll(const ShortTermMemory& stm) {
     Settle();
-    Check("gmx_indirect_learn", gmx_indirect_learn(h_, 0, stm.new_bit));
+    Unstage();
+    MixerPool::Stream& s = st();
+    if (s.ra) {
+      s.ibits[s.t] = (uint8_t)stm.new_bit;  // Indirect::Learn x 41, recorded
+      return;
+    }
+    Call("gmx_indirect_learn", [&] { return gmx_indirect_learn(h_, slot_, stm.new_bit); });
   }
-  void CopyFrom(GpuIndirectBank& o) {
-    o.Settle();
-    Ensure();
-    import_pending_ = false;
-    Check("gmx_indirect_copy", gmx_indirect_copy(h_, 0, o.h_, 0));
-  }
+  void CopyFrom(GpuIndirectBank& o);
 
   ShortTermMemory& stm_;
   LongTermMemory& ltm_;
+  std::shared_ptr<MixerPool> pool_;
+  int slot_ = 0;
   gmx_indirect* h_ = nullptr;
   std::vector<gmx_indirect_desc> descs_;
   std::vector<GpuIndirect*> models_;
@@ -972,7 +1039,7 @@ class GpuIndirectBank : public ChainProducer {
   std::vector<uint32_t> contexts_;
   std::vector<float> pred_;
   std::vector<uint8_t> active_;
-  bool import_pending_ = false;
+  bool import_pending_ = false, tables_staged_ = false;
   bool pending_ = false;  // this bit's Predict waits for the mixers' (gmx_chain_forward)
   uint32_t pending_bit_context_ = 0;
 };
@@ -983,12 +1050,12 @@ class GpuIndirect : public Model {
   GpuIndirect(ShortTermMemory& short_term_memory, LongTermMemory& long_term_memory, float learning_rate,
               unsigned int table_size, unsigned int& context, std::string description, bool enable_analysis)
       : context_(context), bank_(GpuIndirectBank::For(short_term_memory, long_term_memory)) {
-    // indirect.cpp:10-26: the registrations Indirect::Indirect makes (the tables in LongTermMemory are
-    // the staging area of the reference's serialisers here, as they are for the mixers)
+    // indirect.cpp:10-26: the registrations Indirect::Indirect makes.  The tables in LongTermMemory are only the
+    // staging area of the reference's serialisers here (as for the mixers) and stay empty until one runs.
     const int a = short_term_memory.AddPrediction(description + "-indirect", enable_analysis, this);
     const int b = short_term_memory.AddPrediction(description + "-run_map", enable_analysis, this);
     const int memory_index = (int)long_term_memory.indirect.size();
-    long_term_memory.indirect.push_back(IndirectMemory(table_size * 256 + 1));
+    long_term_memory.indirect.push_back(IndirectMemory(0));
     for (int i = 0; i < 256; ++i) {
       long_term_memory.indirect.back().nonstationary_predictions[i] = 0;
       long_term_memory.indirect.back().run_map_predictions[i] = 0;
@@ -1007,8 +1074,9 @@ class GpuIndirect : public Model {
   void WriteToDisk(std::ofstream*) override {  // indirect.h:23: nothing in .short; stage for the .long writer
     if (index_ == 0) bank_->Stage();
   }
-  void ReadFromDisk(std::ifstream*) override {
+  void ReadFromDisk(std::ifstream*) override {  // the reference reads the tables next (predictor.cpp:412-416)
     bank_->Ensure();
+    if (index_ == 0) bank_->StagingTables(true);
     bank_->import_pending_ = true;
   }
   void Copy(const MemoryInterface* m) override {
@@ -1016,12 +1084,13 @@ class GpuIndirect : public Model {
     if (index_ == 0) bank_->CopyFrom(*orig->bank_);
   }
   unsigned long long GetMemoryUsage(const ShortTermMemory&, const LongTermMemory&) override {  // indirect.cpp:71-78
-    bank_->Settle();
+    bank_->Ensure();
     uint64_t v = 0;
-    GpuIndirectBank::Check("gmx_indirect_memory_usage", gmx_indirect_memory_usage(bank_->h_, index_, &v));
+    bank_->Call("gmx_indirect_memory_usage", [&] { return gmx_indirect_memory_usage(bank_->h_, index_, &v); });
     return v;
   }
   unsigned int context() const { return context_; }
+  const unsigned int* context_address() const { return &context_; }
 
  private:
   unsigned int& context_;  // aliases a field of the Predictor's blackboard (indirect.h:31)
@@ -1029,23 +1098,48 @@ class GpuIndirect : public Model {
   int index_;
 };
 
+inline void GpuIndirectBank::CopyFrom(GpuIndirectBank& o) {
+  o.Settle();
+  Ensure();
+  import_pending_ = false;
+  if (o.pool_ == pool_) {
+    Call("gmx_indirect_copy", [&] { return gmx_indirect_copy(h_, slot_, o.h_, o.slot_); });
+  } else {
+    MixerPool* a = pool_.get() < o.pool_.get() ? pool_.get() : o.pool_.get();
+    MixerPool* b = pool_.get() < o.pool_.get() ? o.pool_.get() : pool_.get();
+    int rc;
+    {
+      std::lock_guard<std::mutex> la(a->mu_);
+      std::lock_guard<std::mutex> lb(b->mu_);
+      rc = gmx_indirect_copy(h_, slot_, o.h_, o.slot_);
+    }
+    pool_->Check("gmx::GpuIndirect", "gmx_indirect_copy", rc);
+  }
+}
+
 inline void GpuIndirectBank::PredictAll(ShortTermMemory& stm) {
   Settle();
-  for (size_t i = 0; i < models_.size(); ++i) contexts_[i] = models_[i]->context();
-  bool fused = ChainFused();
-  if (fused) {
-    std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
-    fused = ChainConsumers().count(&ltm_) != 0;
+  Unstage();
+  if (pool_->status()) return;
+  MixerPool::Stream& s = st();
+  if (s.ra) {
+    // Indirect::Predict x 41, recorded: the contexts as they stand when the last model is called, bit_context
+    uint32_t* c = s.ictx + (size_t)s.t * models_.size();
+    for (size_t i = 0; i < models_.size(); ++i) c[i] = models_[i]->context();
+    s.ibc[s.t] = stm.bit_context;
+    return;
   }
-  if (fused) {
+  for (size_t i = 0; i < models_.size(); ++i) contexts_[i] = models_[i]->context();
+  if (ChainFused() && s.mixers) {
     // this Predictor's mixers are on the device too and theirs is the next Predict (predictor.cpp:24-28):
-    // they take this bank along (ChainProducer)
+    // they take this bank along (gmx_chain_forward)
     pending_ = true;
     pending_bit_context_ = stm.bit_context;
     return;
   }
-  Check("gmx_indirect_forward",
-        gmx_indirect_forward(h_, 0, contexts_.data(), stm.bit_context, pred_.data(), active_.data()));
+  Call("gmx_indirect_forward", [&] {
+    return gmx_indirect_forward(h_, slot_, contexts_.data(), stm.bit_context, pred_.data(), active_.data());
+  });
   ToBlackboard(stm);
 }
 
@@ -1073,13 +1167,14 @@ inline void GpuIndirectBank::ToBlackboard(ShortTermMemory& stm) {
 
 // LstmModel (models/lstm-model.cpp) with Lstm(256, 256, 50, 1, 100, 0.03, 10) on the device: the byte-level
 // network once per byte through gmx_lstm_forward / gmx_lstm_perceive, the bit-level range coding of
-// the byte distribution (lstm-model.cpp:34-48) on the host as in the reference.
+// the byte distribution (lstm-model.cpp:34-48) on the host as in the reference -- or, running ahead, all of it in
+// gmx_lstm_run on the bytes' recorded PPM distributions.
 class GpuLstmModel : public Model {
  public:
   static constexpr int kCells = 50, kInputs = 563, kHorizon = 100, kOut = 256, kHidden = 51;
   // models/lstm-model.h:11-12
   GpuLstmModel(ShortTermMemory& short_term_memory, LongTermMemory& long_term_memory, bool enable_analysis)
-      : ltm_(long_term_memory), top_(255), mid_(127), bot_(0), probs_(1.0 / 256, 256) {
+      : stm_(short_term_memory), ltm_(long_term_memory), top_(255), mid_(127), bot_(0), probs_(1.0 / 256, 256) {
     // What the constructors behind Lstm(256, 256, 50, 1, 100, 0.03, 10, ltm) do to LongTermMemory
     // (lstm.cpp:26-29, lstm-layer.cpp:57-59, :179-194): the output-layer ring, three gate matrices,
     // their initial values drawn from rand() in the reference's interleaved order.
@@ -1098,19 +1193,36 @@ class GpuLstmModel : public Model {
     }
     prediction_index_ = short_term_memory.AddPrediction("LSTM", enable_analysis, this);
     short_term_memory.models_with_skip_connection.push_back(prediction_index_);
+    pool_ = MixerPool::Attach(&long_term_memory, &slot_);
+    std::lock_guard<std::mutex> lk(pool_->mu_);
+    st().lstm = this;
   }
   ~GpuLstmModel() override {
-    if (h_) gmx_lstm_destroy(h_);
+    {
+      std::lock_guard<std::mutex> lk(pool_->mu_);
+      st().lstm = nullptr;
+    }
+    pool_->Detach(slot_);
   }
   void Predict(ShortTermMemory& short_term_memory, const LongTermMemory&) override {  // lstm-model.cpp:17-49
+    MixerPool::Stream& s = st();
+    if (s.ra) {
+      // Lstm::SetInput + Lstm::Predict at a byte boundary, recorded: the PPM byte distribution as it stands
+      if (short_term_memory.recent_bits == 1)
+        memcpy(s.ppm + (size_t)(s.t / 8) * 256, &short_term_memory.ppm_predictions[0], 1024);
+      return;
+    }
     if (short_term_memory.recent_bits == 1) {
       Settle();
       uint32_t ctx = 0;
-      Check("gmx_lstm_forward", gmx_lstm_forward(h_, 0, (int)short_term_memory.last_byte,
-                                                  &short_term_memory.ppm_predictions[0], &probs_[0], &ctx));
+      Call("gmx_lstm_forward", [&] {
+        return gmx_lstm_forward(h_, slot_, (int)short_term_memory.last_byte, &short_term_memory.ppm_predictions[0],
+                                &probs_[0], &ctx);
+      });
       short_term_memory.lstm_prediction_context = ctx;
       top_ = 255;
       bot_ = 0;
+      range_on_device_ = false;
     } else if (short_term_memory.new_bit) {
       bot_ = mid_ + 1;
     } else {
@@ -1123,24 +1235,32 @@ class GpuLstmModel : public Model {
   }
   void Learn(const ShortTermMemory& short_term_memory, LongTermMemory&) override {  // lstm-model.cpp:51-60
     const int current_byte = short_term_memory.recent_bits * 2 + short_term_memory.new_bit;
-    if (current_byte >= 256) {
-      Settle();
-      Check("gmx_lstm_perceive", gmx_lstm_perceive(h_, 0, current_byte - 256));
+    if (current_byte < 256) return;
+    MixerPool::Stream& s = st();
+    if (s.ra) {
+      s.bytes[s.t / 8] = (uint8_t)(current_byte - 256);  // Lstm::Perceive, recorded
+      return;
     }
+    Settle();
+    Call("gmx_lstm_perceive", [&] { return gmx_lstm_perceive(h_, slot_, current_byte - 256); });
   }
   // lstm-model.cpp:62-68 and everything behind it: the device writes the model's stretch of the .short
   // file; the range state is this object's own.  The LSTM section of the .long file is the reference's
   // to write (long-term-memory.cpp:57-67), from the arrays staged here.
   void WriteToDisk(std::ofstream* s) override {
     Settle();
+    SyncIfAhead();
     size_t nl = 0, ns = 0;
-    Check("gmx_lstm_export", gmx_lstm_export(h_, 0, nullptr, &nl, nullptr, &ns));
-    std::vector<char> l(nl), sh(ns);
-    Check("gmx_lstm_export", gmx_lstm_export(h_, 0, l.data(), &nl, sh.data(), &ns));
-    memcpy(sh.data(), &top_, 4);
-    memcpy(sh.data() + 4, &mid_, 4);
-    memcpy(sh.data() + 8, &bot_, 4);
-    memcpy(sh.data() + 12, &probs_[0], 1024);
+    Call("gmx_lstm_export", [&] { return gmx_lstm_export(h_, slot_, nullptr, &nl, nullptr, &ns); });
+    std::vector<char> l(nl ? nl : 1), sh(ns ? ns : 1);
+    Call("gmx_lstm_export", [&] { return gmx_lstm_export(h_, slot_, l.data(), &nl, sh.data(), &ns); });
+    if (pool_->status()) return;
+    if (!range_on_device_) {  // (after a stretch of run-ahead the device's own copy of these is the current one)
+      memcpy(sh.data(), &top_, 4);
+      memcpy(sh.data() + 4, &mid_, 4);
+      memcpy(sh.data() + 8, &bot_, 4);
+      memcpy(sh.data() + 12, &probs_[0], 1024);
+    }
     s->write(sh.data(), ns);
     const float* f = reinterpret_cast<const float*>(l.data());
     for (auto& x : ltm_.lstm_output_layer)
@@ -1156,41 +1276,62 @@ class GpuLstmModel : public Model {
   }
   void ReadFromDisk(std::ifstream* s) override {  // lstm-model.cpp:70-76
     Ensure();
+    SyncIfAhead();
     size_t nl = 0, ns = 0;
-    Check("gmx_lstm_export", gmx_lstm_export(h_, 0, nullptr, &nl, nullptr, &ns));
+    Call("gmx_lstm_export", [&] { return gmx_lstm_export(h_, slot_, nullptr, &nl, nullptr, &ns); });
     short_in_.resize(ns);
     s->read(short_in_.data(), ns);
-    memcpy(&top_, short_in_.data(), 4);
-    memcpy(&mid_, short_in_.data() + 4, 4);
-    memcpy(&bot_, short_in_.data() + 8, 4);
-    memcpy(&probs_[0], short_in_.data() + 12, 1024);
+    if (ns >= 12 + 1024) {
+      memcpy(&top_, short_in_.data(), 4);
+      memcpy(&mid_, short_in_.data() + 4, 4);
+      memcpy(&bot_, short_in_.data() + 8, 4);
+      memcpy(&probs_[0], short_in_.data() + 12, 1024);
+    }
+    range_on_device_ = false;
     import_pending_ = true;  // the weights follow when LongTermMemory::ReadFromDisk has run
   }
   void Copy(const MemoryInterface* m) override {  // lstm-model.cpp:78-85
     GpuLstmModel* orig = const_cast<GpuLstmModel*>(static_cast<const GpuLstmModel*>(m));
     orig->Settle();
+    orig->SyncIfAhead();
     Ensure();
+    SyncIfAhead();
     import_pending_ = false;
-    Check("gmx_lstm_copy", gmx_lstm_copy(h_, 0, orig->h_, 0));
+    if (orig->pool_ == pool_) {
+      Call("gmx_lstm_copy", [&] { return gmx_lstm_copy(h_, slot_, orig->h_, orig->slot_); });
+    } else {
+      MixerPool* a = pool_.get() < orig->pool_.get() ? pool_.get() : orig->pool_.get();
+      MixerPool* b = pool_.get() < orig->pool_.get() ? orig->pool_.get() : pool_.get();
+      int rc;
+      {
+        std::lock_guard<std::mutex> la(a->mu_);
+        std::lock_guard<std::mutex> lb(b->mu_);
+        rc = gmx_lstm_copy(h_, slot_, orig->h_, orig->slot_);
+      }
+      pool_->Check("gmx::GpuLstmModel", "gmx_lstm_copy", rc);
+    }
     top_ = orig->top_;
     mid_ = orig->mid_;
     bot_ = orig->bot_;
     probs_ = orig->probs_;
+    range_on_device_ = orig->range_on_device_;
   }
   unsigned long long GetMemoryUsage(const ShortTermMemory&, const LongTermMemory&) override {
     Ensure();
     uint64_t v = 0;
-    Check("gmx_lstm_memory_usage", gmx_lstm_memory_usage(h_, &v));
+    Call("gmx_lstm_memory_usage", [&] { return gmx_lstm_memory_usage(h_, &v); });
     return v;
   }
+  int prediction_index() const { return prediction_index_; }
 
  private:
-  static void Check(const char* what, int rc) {
-    if (rc == GMX_OK) return;
-    fprintf(stderr, "\ngmx::GpuLstmModel: %s: %s %s\n(the LSTM runs on an MI355X through libgmxmix.so; there is no CPU fallback)\n",
-            what, gmx_strerror(rc), rc == GMX_ERR_HIP ? gmx_last_error() : "");
-    abort();
+  friend class GpuMixerBank;
+  MixerPool::Stream& st() { return pool_->streams_[slot_]; }
+  template <class F>
+  void Call(const char* what, F f) {
+    pool_->Call("gmx::GpuLstmModel", what, f);
   }
+  void SyncIfAhead();
   std::vector<char> LongBytes() const {  // the LSTM section as LongTermMemory writes it
     std::vector<char> l;
     auto put = [&l](const std::valarray<float>& y) {
@@ -1205,31 +1346,175 @@ class GpuLstmModel : public Model {
   }
   void Ensure() {
     if (h_) return;
-    const char* dev = getenv("GMX_DEVICE");
-    Check("gmx_lstm_create", gmx_lstm_create(&h_, 1, dev ? atoi(dev) : 0));
+    Call("gmx_lstm_create", [&] { return pool_->EnsureLstm(); });
+    h_ = pool_->lstm();
     std::vector<float> w((size_t)3 * kCells * kInputs);
     for (int g = 0; g < 3; ++g)
       for (int i = 0; i < kCells; ++i)
         memcpy(&w[((size_t)g * kCells + i) * kInputs], &ltm_.neuron_layer_weights[first_layer_ + g].weights[i][0],
                4 * kInputs);
-    Check("gmx_lstm_set_weights", gmx_lstm_set_weights(h_, 0, w.data()));
+    Call("gmx_lstm_set_weights", [&] { return gmx_lstm_set_weights(h_, slot_, w.data()); });
   }
   void Settle() {
     Ensure();
     if (!import_pending_) return;
     import_pending_ = false;
     std::vector<char> l = LongBytes();
-    Check("gmx_lstm_import", gmx_lstm_import(h_, 0, l.data(), l.size(), short_in_.data(), short_in_.size()));
+    Call("gmx_lstm_import",
+         [&] { return gmx_lstm_import(h_, slot_, l.data(), l.size(), short_in_.data(), short_in_.size()); });
   }
 
+  ShortTermMemory& stm_;
   LongTermMemory& ltm_;
+  std::shared_ptr<MixerPool> pool_;
+  int slot_ = 0;
   gmx_lstm* h_ = nullptr;
   int first_layer_ = 0;
   int top_, mid_, bot_, prediction_index_;
   std::valarray<float> probs_;
   std::vector<char> short_in_;
   bool import_pending_ = false;
+  bool range_on_device_ = false;  // top_/mid_/bot_/probs_ were last advanced by the device (run-ahead)
 };
+
+// ---- the parts of the mixers' bank that know the other two ---------------------------------------------------
+inline void GpuLstmModel::SyncIfAhead() {
+  MixerPool::Stream& s = st();
+  if (s.ra && s.mixers) s.mixers->SyncRunAhead();
+}
+
+inline std::vector<int> GpuMixerBank::IndirectSlots() const {
+  std::vector<int> v;
+  const GpuIndirectBank* ib = pool_->streams_[slot_].indirect;
+  if (ib)
+    for (auto& d : ib->descs_) {
+      v.push_back(d.slot_indirect);
+      v.push_back(d.slot_run_map);
+    }
+  return v;
+}
+inline int GpuMixerBank::LstmSlot() const {
+  const GpuLstmModel* l = pool_->streams_[slot_].lstm;
+  return l ? l->prediction_index() : -1;
+}
+
+inline int GpuMixerBank::BeginRunAhead(RunAheadSink* sink, uint64_t chunk_bits) {
+  if (st().ra) return GMX_ERR_STATE;
+  Settle();
+  MixerPool::Stream& s = st();
+  int parts = MixerPool::kMixers, lstm_slot = -1, mixer_ctx_col = -1, ind_ctx_col = -1;
+  if (s.indirect) {
+    s.indirect->Settle();
+    s.indirect->pending_ = false;
+    parts |= MixerPool::kIndirect;
+  }
+  if (s.lstm) {
+    // the run-ahead LSTM works on whole bytes, and hands over what hangs on ShortTermMemory::lstm_prediction_context:
+    // a gate context of the mixers (predictor.cpp:321) and the context of one Indirect model (predictor.cpp:117-119)
+    if (stm_.recent_bits != 1 && stm_.bits_seen > 0) return GMX_ERR_STATE;
+    s.lstm->Settle();
+    parts |= MixerPool::kLstm;
+    lstm_slot = s.lstm->prediction_index();
+    for (size_t j = 0; j < mixers_.size(); ++j)
+      if (mixers_[j]->context_address() == &stm_.lstm_prediction_context) mixer_ctx_col = (int)j;
+    if (s.indirect)
+      for (size_t i = 0; i < s.indirect->models_.size(); ++i)
+        if (s.indirect->models_[i]->context_address() == &stm_.lstm_prediction_context) ind_ctx_col = (int)i;
+  }
+  if (status()) return status();
+  lstm_ctx_col_ = mixer_ctx_col;
+  // rows this bank has seen (Mixer::contexts_seen_ / GetMemoryUsage while the device runs behind)
+  seen_.assign(descs_.size(), std::vector<uint64_t>());
+  seen_count_.assign(descs_.size(), 0);
+  for (size_t j = 0; j < descs_.size(); ++j) seen_[j].assign(((size_t)descs_[j].table_size + 63) / 64, 0);
+  if (ever_ran_) {
+    Stage();
+    for (size_t j = 0; j < descs_.size(); ++j) {
+      auto& table = ltm_.mixers[memory_index_[j]].mixer_table;
+      for (size_t c = 0; c < table.size(); ++c)
+        if (table[c]) {
+          seen_[j][c >> 6] |= 1ull << (c & 63);
+          ++seen_count_[j];
+        }
+    }
+    Unstage();
+  }
+  int rc = pool_->Join(slot_, chunk_bits, parts, lstm_slot, mixer_ctx_col, ind_ctx_col, sink && sink->WantsModels());
+  if (rc) return rc;
+  T_ = pool_->chunk_bits();
+  n_pad_ = pool_->n_pad_;
+  mask_words_ = pool_->mask_words_;
+  recorded_ = false;
+  sink_ = sink;
+  ever_ran_ = true;
+  return GMX_OK;
+}
+
+inline int GpuMixerBank::Flush() {
+  RunAheadView v;
+  int rc = pool_->Arrive(slot_, st().t, &v);
+  if (rc) return rc;
+  if (v.n) {
+    if (sink_) sink_->Drain(v);
+    // mixer.cpp:99-105: where the Mixer::Predict calls of the newest bit left their results
+    const int M = v.n_mixers;
+    const float* o = v.outputs + (size_t)(v.n - 1) * M;
+    size_t j = 0;
+    for (int k = 0; k < stm_.num_layer0_mixers; ++k) stm_.mixer_layer0_outputs[k] = o[j++];
+    for (int k = 0; k < stm_.num_layer1_mixers; ++k) stm_.mixer_layer1_outputs[k] = o[j++];
+    if (j < (size_t)M) stm_.final_mixer_output = o[j];
+    if (st().lstm) st().lstm->range_on_device_ = true;
+  }
+  return GMX_OK;
+}
+
+inline void GpuMixerBank::PredictAll(ShortTermMemory& stm) {
+  Settle();
+  if (status()) return;
+  MixerPool::Stream& s = st();
+  if (s.ra) {
+    // Mixer::Predict x 33, recorded: the raw blackboard, active_models as a mask, the contexts read now
+    if (recorded_) {  // a Predict whose bit was never learned: not a path that runs ahead
+      Check("run-ahead needs Predict -> Perceive -> Learn for every bit", GMX_ERR_STATE);
+      return;
+    }
+    const int N = stm.num_predictions;
+    memcpy(s.pred + (size_t)s.t * n_pad_, &stm.predictions[0], 4 * (size_t)N);
+    uint32_t* m = s.mask + (size_t)s.t * mask_words_;
+    for (int w = 0; w < mask_words_; ++w) m[w] = 0;
+    for (int idx : stm.active_models) m[idx >> 5] |= 1u << (idx & 31);
+    uint32_t* c = s.ctx + (size_t)s.t * mixers_.size();
+    for (size_t j = 0; j < mixers_.size(); ++j) c[j] = mixers_[j]->context();
+    recorded_ = true;
+    return;
+  }
+  for (size_t j = 0; j < mixers_.size(); ++j) contexts_[j] = mixers_[j]->context();  // read at call time
+  static_assert(sizeof(int) == sizeof(int32_t), "active_models is passed as it stands");
+  float p = 0.5f;
+  GpuIndirectBank* ind = (s.indirect && s.indirect->pending_) ? s.indirect : nullptr;
+  ever_ran_ = true;
+  if (ind) {
+    // the Indirect models' Predict of this bit is still to run: both banks in one round trip
+    chain_pred_.resize(128);  // two slots for each of at most 64 models (gmx_indirect_create's limit)
+    chain_act_.resize(128);
+    Call("gmx_chain_forward", [&] {
+      return gmx_chain_forward(ind->h_, group_, slot_, ind->contexts_.data(), ind->pending_bit_context_,
+                               &stm.predictions[0], stm.active_models.data(), (int)stm.active_models.size(),
+                               contexts_.data(), &p, outputs_.data(), chain_pred_.data(), chain_act_.data());
+    });
+    ind->Deliver(stm, chain_pred_.data(), chain_act_.data());
+  } else {
+    Call("gmx_bank_forward", [&] {
+      return gmx_bank_forward(group_, slot_, &stm.predictions[0], stm.active_models.data(),
+                              (int)stm.active_models.size(), contexts_.data(), &p, outputs_.data());
+    });
+  }
+  // mixer.cpp:99-105: where each Mixer::Predict leaves its result
+  size_t j = 0;
+  for (int k = 0; k < stm.num_layer0_mixers; ++k) stm.mixer_layer0_outputs[k] = outputs_[j++];
+  for (int k = 0; k < stm.num_layer1_mixers; ++k) stm.mixer_layer1_outputs[k] = outputs_[j++];
+  if (j < outputs_.size()) stm.final_mixer_output = outputs_[j];
+}
 
 }  // namespace gmx
 

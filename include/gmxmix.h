@@ -292,6 +292,10 @@ int gmx_ind_batch_fill_synthetic(gmx_ind_batch* b, uint64_t n_bits, uint64_t see
 int gmx_indirect_run(gmx_indirect* ib, gmx_ind_batch* b, uint64_t n_bits, int learn, gmx_batch* into,
                      float* kernel_ms);
 
+/* ... for streams at different lengths (cf. gmx_group_run_ragged): stream s runs bits [0, n_bits[s]). */
+int gmx_indirect_run_ragged(gmx_indirect* ib, gmx_ind_batch* b, const uint64_t* n_bits /* [S] */, int learn,
+                            gmx_batch* into);
+
 /* The indirect section of LongTermMemory::WriteToDisk / ReadFromDisk (long-term-memory.cpp:8-32,
  * :111-132), byte for byte; NULL buf to size.  Copy = long-term-memory.cpp:193-199;
  * memory_usage = Indirect::GetMemoryUsage (indirect.cpp:71-78). */
@@ -339,6 +343,8 @@ int gmx_lstm_batch_wait(gmx_lstm_batch* b);                /* this batch's uploa
 /* LstmModel::Predict x 8 bits (+ LstmModel::Learn when learn != 0) for bytes [0, n_bytes) of every
  * stream. */
 int gmx_lstm_run(gmx_lstm* l, gmx_lstm_batch* b, uint64_t n_bytes, int learn, float* kernel_ms);
+/* ... for streams at different lengths (cf. gmx_group_run_ragged): stream s runs bytes [0, n_bytes[s]). */
+int gmx_lstm_run_ragged(gmx_lstm* l, gmx_lstm_batch* b, const uint64_t* n_bytes /* [S] */, int learn);
 /* Per-byte surface, for decoding (the byte is not known when its prediction is needed).
  * forward = Lstm::SetInput + Lstm::Predict(last_byte) at a byte boundary (lstm-model.cpp:19-33,
  * last_byte = ShortTermMemory::last_byte): probs[256]

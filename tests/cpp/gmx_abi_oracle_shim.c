@@ -101,6 +101,8 @@ void gmx_batch_destroy(gmx_batch* b) {
   free(b);
 }
 int gmx_batch_n_pad(const gmx_batch* b) { return b->n_pad; }
+uint64_t gmx_batch_max_bits(const gmx_batch* b) { return b->T; }
+int gmx_shim_batch_m(const gmx_batch* b) { return b->g->m; } /* for gmx_lstm_feed in gmx_abi_oracle_shim2.c */
 int gmx_batch_mask_words(const gmx_batch* b) { return b->mw; }
 float* gmx_batch_predictions(gmx_batch* b) { return b->pred; }
 uint32_t* gmx_batch_active_mask(gmx_batch* b) { return b->mask; }
@@ -136,7 +138,7 @@ extern int gmx_shim_indirect_slots(gmx_indirect* ib, int* n, const int (**slots)
 int gmx_chain_forward(gmx_indirect* ib, gmx_group* g, int stream, const uint32_t* ind_contexts, uint32_t bit_context,
                       const float* predictions, const int32_t* active_models, int n_active, const uint32_t* contexts,
                       float* p_final, float* out_all, float* ind_predictions, uint8_t* ind_active) {
-  if (!gmx_indirect_forward || !gmx_shim_indirect_slots || !ib || !g || stream != 0 || n_active < 0) return GMX_ERR_INVALID;
+  if (!gmx_indirect_forward || !gmx_shim_indirect_slots || !ib || !g || stream < 0 || stream >= g->S || n_active < 0) return GMX_ERR_INVALID;
   int k = 0;
   const int (*slots)[2] = 0;
   gmx_shim_indirect_slots(ib, &k, &slots);

@@ -9,10 +9,12 @@
 
 /* ---- Indirect ---------------------------------------------------------------------------------- */
 struct gmx_indirect {
-  gmxo_ind* b;
-  int n;
+  gmxo_ind** bs; /* one oracle bank per stream */
+  gmxo_ind* b;   /* == bs[0] */
+  int S, n;
   int slot[64][2];
 };
+#define IND_BANK(ib, stream) ((ib) && (stream) >= 0 && (stream) < (ib)->S ? (ib)->bs[stream] : 0)
 /* for gmx_chain_forward in gmx_abi_oracle_shim.c: where the models' predictions go on the blackboard */
 int gmx_shim_indirect_slots(gmx_indirect* ib, int* n, const int (**slots)[2]) {
   *n = ib->n;
@@ -23,7 +25,7 @@ int gmx_shim_indirect_slots(gmx_indirect* ib, int* n, const int (**slots)[2]) {
 int gmx_indirect_create(gmx_indirect** out, const gmx_indirect_desc* models, int n_models, const uint8_t* ns_next,
                         const uint8_t* rm_next, int n_streams, int device) {
   (void)device;
-  if (!out || n_streams != 1 || n_models > 64) return GMX_ERR_INVALID;
+  if (!out || n_streams < 1 || n_models > 64) return GMX_ERR_INVALID;
   uint32_t ts[64];
   float lr[64];
   for (int i = 0; i < n_models; ++i) {
@@ -36,40 +38,44 @@ int gmx_indirect_create(gmx_indirect** out, const gmx_indirect_desc* models, int
     ib->slot[i][0] = models[i].slot_indirect;
     ib->slot[i][1] = models[i].slot_run_map;
   }
-  ib->b = gmxo_ind_create(n_models, ts, lr, ns_next, rm_next);
+  ib->S = n_streams;
+  ib->bs = (gmxo_ind**)calloc((size_t)n_streams, sizeof(gmxo_ind*));
+  for (int s = 0; s < n_streams; ++s) ib->bs[s] = gmxo_ind_create(n_models, ts, lr, ns_next, rm_next);
+  ib->b = ib->bs[0];
   *out = ib;
   return GMX_OK;
 }
 void gmx_indirect_destroy(gmx_indirect* ib) {
   if (!ib) return;
-  gmxo_ind_destroy(ib->b);
+  for (int s = 0; s < ib->S; ++s) gmxo_ind_destroy(ib->bs[s]);
+  free(ib->bs);
   free(ib);
 }
 int gmx_indirect_forward(gmx_indirect* ib, int stream, const uint32_t* contexts, uint32_t bit_context, float* predictions,
                          uint8_t* active) {
-  if (!ib || stream) return GMX_ERR_INVALID;
-  gmxo_ind_predict(ib->b, contexts, bit_context, predictions, active);
+  if (!IND_BANK(ib, stream)) return GMX_ERR_INVALID;
+  gmxo_ind_predict(ib->bs[stream], contexts, bit_context, predictions, active);
   return GMX_OK;
 }
 int gmx_indirect_learn(gmx_indirect* ib, int stream, int bit) {
-  if (!ib || stream) return GMX_ERR_INVALID;
-  gmxo_ind_learn(ib->b, bit);
+  if (!IND_BANK(ib, stream)) return GMX_ERR_INVALID;
+  gmxo_ind_learn(ib->bs[stream], bit);
   return GMX_OK;
 }
 int gmx_indirect_export(gmx_indirect* ib, int stream, void* buf, size_t* bytes) {
-  if (!ib || stream || !bytes) return GMX_ERR_INVALID;
-  const size_t n = gmxo_ind_export(ib->b, 0, 0);
-  if (buf) gmxo_ind_export(ib->b, (uint8_t*)buf, n);
+  if (!IND_BANK(ib, stream) || !bytes) return GMX_ERR_INVALID;
+  const size_t n = gmxo_ind_export(ib->bs[stream], 0, 0);
+  if (buf) gmxo_ind_export(ib->bs[stream], (uint8_t*)buf, n);
   *bytes = n;
   return GMX_OK;
 }
 /* the indirect section of LongTermMemory::ReadFromDisk (long-term-memory.cpp:111-132) into a bank */
 int gmx_indirect_import(gmx_indirect* ib, int stream, const void* buf, size_t bytes) {
-  if (!ib || stream) return GMX_ERR_INVALID;
+  if (!IND_BANK(ib, stream)) return GMX_ERR_INVALID;
   const uint8_t* p = (const uint8_t*)buf;
   const uint8_t* end = p + bytes;
   for (int i = 0; i < ib->b->k; ++i) {
-    ind_model* m = &ib->b->m[i];
+    ind_model* m = &ib->bs[stream]->m[i];
     if (end - p < 4) return GMX_ERR_FORMAT;
     uint32_t cnt;
     memcpy(&cnt, p, 4);
@@ -100,16 +106,16 @@ int gmx_indirect_import(gmx_indirect* ib, int stream, const void* buf, size_t by
   return p == end ? GMX_OK : GMX_ERR_FORMAT;
 }
 int gmx_indirect_copy(gmx_indirect* dst, int ds, gmx_indirect* src, int ss) {
-  if (!dst || !src || ds || ss || dst->b->k != src->b->k) return GMX_ERR_INVALID;
+  if (!IND_BANK(dst, ds) || !IND_BANK(src, ss) || dst->b->k != src->b->k) return GMX_ERR_INVALID;
   for (int i = 0; i < dst->b->k; ++i) {
-    ind_model *a = &dst->b->m[i], *b = &src->b->m[i];
+    ind_model *a = &dst->bs[ds]->m[i], *b = &src->bs[ss]->m[i];
     if (a->size != b->size) return GMX_ERR_INVALID;
     memcpy(a->ns, b->ns, a->size);
     memcpy(a->rm, b->rm, a->size);
     memcpy(a->nsp, b->nsp, sizeof a->nsp);
     memcpy(a->rmp, b->rmp, sizeof a->rmp);
   }
-  memcpy(dst->b->pred, src->b->pred, 2 * dst->b->k * sizeof(float));
+  memcpy(dst->bs[ds]->pred, src->bs[ss]->pred, 2 * dst->b->k * sizeof(float));
   return GMX_OK;
 }
 int gmx_indirect_memory_usage(gmx_indirect* ib, int model, uint64_t* bytes) {
@@ -119,72 +125,97 @@ int gmx_indirect_memory_usage(gmx_indirect* ib, int model, uint64_t* bytes) {
 }
 
 /* ---- LSTM -------------------------------------------------------------------------------------- */
-struct gmx_lstm {
+/* the byte the last Lstm::Perceive stored (lstm.cpp:53-55): what a bank remembers as last_byte after an import */
+static uint32_t gmxo_lstm_last_input(const gmxo_lstm* l) {
+  int last_epoch = (int)l->epoch - 1;
+  if (last_epoch == -1) last_epoch = H - 1;
+  return l->input_history[last_epoch];
+}
+typedef struct lstm_stream {
   gmxo_lstm* l;
   int forward_pending; /* the product refuses checkpoints between forward and perceive: so does this */
+  uint32_t last_byte, context; /* what the bank remembers between batched runs */
+  float prediction;
+} lstm_stream;
+struct gmx_lstm {
+  lstm_stream* st;
+  int S;
 };
+#define LSTM_ST(l, stream) ((l) && (stream) >= 0 && (stream) < (l)->S ? &(l)->st[stream] : 0)
 
 int gmx_lstm_create(gmx_lstm** out, int n_streams, int device) {
   (void)device;
-  if (!out || n_streams != 1) return GMX_ERR_INVALID;
+  if (!out || n_streams < 1) return GMX_ERR_INVALID;
   gmx_lstm* l = (gmx_lstm*)calloc(1, sizeof *l);
-  l->l = gmxo_lstm_create();
+  l->S = n_streams;
+  l->st = (lstm_stream*)calloc((size_t)n_streams, sizeof(lstm_stream));
+  for (int s = 0; s < n_streams; ++s) l->st[s].l = gmxo_lstm_create();
   *out = l;
   return GMX_OK;
 }
 void gmx_lstm_destroy(gmx_lstm* l) {
   if (!l) return;
-  gmxo_lstm_destroy(l->l);
+  for (int s = 0; s < l->S; ++s) gmxo_lstm_destroy(l->st[s].l);
+  free(l->st);
   free(l);
 }
 int gmx_lstm_set_weights(gmx_lstm* l, int stream, const float* weights) {
-  if (!l || stream) return GMX_ERR_INVALID;
-  gmxo_lstm_set_weights(l->l, weights);
+  if (!LSTM_ST(l, stream)) return GMX_ERR_INVALID;
+  gmxo_lstm_set_weights(l->st[stream].l, weights);
   return GMX_OK;
 }
 int gmx_lstm_forward(gmx_lstm* l, int stream, int last_byte, const float* ppm, float* probs, uint32_t* context) {
-  if (!l || stream) return GMX_ERR_INVALID;
+  if (!LSTM_ST(l, stream)) return GMX_ERR_INVALID;
   float pr[256];
   uint32_t ctx = 0;
-  gmxo_lstm_predict_byte(l->l, ppm, (uint32_t)last_byte, pr, &ctx);
+  gmxo_lstm_predict_byte(l->st[stream].l, ppm, (uint32_t)last_byte, pr, &ctx);
   if (probs) memcpy(probs, pr, sizeof pr);
   if (context) *context = ctx;
-  l->forward_pending = 1;
+  l->st[stream].context = ctx;
+  l->st[stream].forward_pending = 1;
   return GMX_OK;
 }
 int gmx_lstm_perceive(gmx_lstm* l, int stream, int byte) {
-  if (!l || stream) return GMX_ERR_INVALID;
-  gmxo_lstm_perceive_byte(l->l, (uint32_t)byte);
-  l->forward_pending = 0;
+  if (!LSTM_ST(l, stream)) return GMX_ERR_INVALID;
+  gmxo_lstm_perceive_byte(l->st[stream].l, (uint32_t)byte);
+  l->st[stream].last_byte = (uint32_t)byte;
+  l->st[stream].forward_pending = 0;
   return GMX_OK;
 }
 int gmx_lstm_export(gmx_lstm* l, int stream, void* long_buf, size_t* long_bytes, void* short_buf, size_t* short_bytes) {
-  if (!l || stream) return GMX_ERR_INVALID;
-  if ((long_buf || short_buf) && l->forward_pending) return GMX_ERR_STATE;
-  *long_bytes = gmxo_lstm_export_long(l->l, 0);
-  *short_bytes = gmxo_lstm_export_short(l->l, 0);
-  if (long_buf) gmxo_lstm_export_long(l->l, (uint8_t*)long_buf);
-  if (short_buf) gmxo_lstm_export_short(l->l, (uint8_t*)short_buf);
+  if (!LSTM_ST(l, stream)) return GMX_ERR_INVALID;
+  lstm_stream* st = &l->st[stream];
+  if ((long_buf || short_buf) && st->forward_pending) return GMX_ERR_STATE;
+  *long_bytes = gmxo_lstm_export_long(st->l, 0);
+  *short_bytes = gmxo_lstm_export_short(st->l, 0);
+  if (long_buf) gmxo_lstm_export_long(st->l, (uint8_t*)long_buf);
+  if (short_buf) gmxo_lstm_export_short(st->l, (uint8_t*)short_buf);
   return GMX_OK;
 }
 int gmx_lstm_import(gmx_lstm* l, int stream, const void* long_buf, size_t long_bytes, const void* short_buf,
                     size_t short_bytes) {
-  if (!l || stream) return GMX_ERR_INVALID;
-  if (gmxo_lstm_import_long(l->l, (const uint8_t*)long_buf, long_bytes)) return GMX_ERR_FORMAT;
-  if (gmxo_lstm_import_short(l->l, (const uint8_t*)short_buf, short_bytes)) return GMX_ERR_FORMAT;
-  l->forward_pending = 0;
+  if (!LSTM_ST(l, stream)) return GMX_ERR_INVALID;
+  lstm_stream* st = &l->st[stream];
+  if (gmxo_lstm_import_long(st->l, (const uint8_t*)long_buf, long_bytes)) return GMX_ERR_FORMAT;
+  if (gmxo_lstm_import_short(st->l, (const uint8_t*)short_buf, short_bytes)) return GMX_ERR_FORMAT;
+  st->forward_pending = 0;
+  st->last_byte = gmxo_lstm_last_input(st->l); /* the newest entry of input_history_ (include/gmxmix.h) */
   return GMX_OK;
 }
 int gmx_lstm_copy(gmx_lstm* dst, int ds, gmx_lstm* src, int ss) {
-  if (!dst || !src || ds || ss) return GMX_ERR_INVALID;
-  const size_t nl = gmxo_lstm_export_long(src->l, 0), ns = gmxo_lstm_export_short(src->l, 0);
+  if (!LSTM_ST(dst, ds) || !LSTM_ST(src, ss)) return GMX_ERR_INVALID;
+  lstm_stream *d = &dst->st[ds], *sr = &src->st[ss];
+  const size_t nl = gmxo_lstm_export_long(sr->l, 0), ns = gmxo_lstm_export_short(sr->l, 0);
   uint8_t* a = (uint8_t*)malloc(nl);
   uint8_t* b = (uint8_t*)malloc(ns);
-  gmxo_lstm_export_long(src->l, a);
-  gmxo_lstm_export_short(src->l, b);
-  gmxo_lstm_import_long(dst->l, a, nl);
-  gmxo_lstm_import_short(dst->l, b, ns);
-  dst->forward_pending = src->forward_pending;
+  gmxo_lstm_export_long(sr->l, a);
+  gmxo_lstm_export_short(sr->l, b);
+  gmxo_lstm_import_long(d->l, a, nl);
+  gmxo_lstm_import_short(d->l, b, ns);
+  d->forward_pending = sr->forward_pending;
+  d->last_byte = sr->last_byte;
+  d->context = sr->context;
+  d->prediction = sr->prediction;
   free(a);
   free(b);
   return GMX_OK;
@@ -193,5 +224,157 @@ int gmx_lstm_memory_usage(gmx_lstm* l, uint64_t* bytes) {
   if (!l) return GMX_ERR_INVALID;
   *bytes = 7017924ull; /* LstmModel::GetMemoryUsage (lstm-model.cpp:87-101): a constant of the architecture, the value
                           the reference's own model reports in tests/golden/lstm_*.npz */
+  return GMX_OK;
+}
+
+/* ---- the batched surfaces the run-ahead compressor uses with the whole chain on the device
+ * (gmix_amd/host/gmx_model_adapter.h, MixerPool::Lead): plain host arrays; the "device work" is done by the oracle when
+ * the run / feed calls are made, in the order the product queues it ---- */
+int gmx_indirect_n_models(const gmx_indirect* ib) { return ib ? ib->n : GMX_ERR_INVALID; }
+struct gmx_ind_batch {
+  gmx_indirect* ib;
+  uint64_t T;
+  uint32_t *ctx, *bc;
+  uint8_t *bits, *act;
+  float* pred;
+};
+int gmx_ind_batch_create(gmx_ind_batch** out, gmx_indirect* ib, uint64_t max_bits) {
+  if (!out || !ib || !max_bits) return GMX_ERR_INVALID;
+  gmx_ind_batch* b = (gmx_ind_batch*)calloc(1, sizeof *b);
+  const size_t R = (size_t)ib->S * max_bits;
+  b->ib = ib;
+  b->T = max_bits;
+  b->ctx = (uint32_t*)calloc(R * ib->n, 4);
+  b->bc = (uint32_t*)calloc(R, 4);
+  b->bits = (uint8_t*)calloc(R, 1);
+  b->pred = (float*)calloc(R * 2 * ib->n, 4);
+  b->act = (uint8_t*)calloc(R * 2 * ib->n, 1);
+  *out = b;
+  return GMX_OK;
+}
+void gmx_ind_batch_destroy(gmx_ind_batch* b) {
+  if (!b) return;
+  free(b->ctx);
+  free(b->bc);
+  free(b->bits);
+  free(b->pred);
+  free(b->act);
+  free(b);
+}
+uint32_t* gmx_ind_batch_contexts(gmx_ind_batch* b) { return b->ctx; }
+uint32_t* gmx_ind_batch_bit_contexts(gmx_ind_batch* b) { return b->bc; }
+uint8_t* gmx_ind_batch_bits(gmx_ind_batch* b) { return b->bits; }
+const float* gmx_ind_batch_predictions(gmx_ind_batch* b) { return b->pred; }
+const uint8_t* gmx_ind_batch_active(gmx_ind_batch* b) { return b->act; }
+int gmx_ind_batch_upload(gmx_ind_batch* b, uint64_t n) { return (b && n <= b->T) ? GMX_OK : GMX_ERR_INVALID; }
+int gmx_ind_batch_download(gmx_ind_batch* b, uint64_t n) { return (b && n <= b->T) ? GMX_OK : GMX_ERR_INVALID; }
+int gmx_ind_batch_wait(gmx_ind_batch* b) { return b ? GMX_OK : GMX_ERR_INVALID; }
+/* the mixer batch's arrays (gmx_abi_oracle_shim.c) */
+extern float* gmx_batch_predictions(gmx_batch* b);
+extern uint32_t* gmx_batch_active_mask(gmx_batch* b);
+extern uint32_t* gmx_batch_contexts(gmx_batch* b);
+extern uint8_t* gmx_batch_bits(gmx_batch* b);
+extern int gmx_batch_n_pad(const gmx_batch* b);
+extern int gmx_batch_mask_words(const gmx_batch* b);
+extern uint64_t gmx_batch_max_bits(const gmx_batch* b);
+extern int gmx_shim_batch_m(const gmx_batch* b);
+int gmx_indirect_run_ragged(gmx_indirect* ib, gmx_ind_batch* b, const uint64_t* n_bits, int learn, gmx_batch* into) {
+  if (!ib || !b || b->ib != ib || !n_bits) return GMX_ERR_INVALID;
+  const int k = ib->n;
+  for (int s = 0; s < ib->S; ++s) {
+    if (n_bits[s] > b->T) return GMX_ERR_INVALID;
+    const size_t r0 = (size_t)s * b->T;
+    gmxo_ind_run(ib->bs[s], n_bits[s], b->ctx + r0 * k, b->bc + r0, b->bits + r0, learn ? n_bits[s] : 0,
+                 b->pred + r0 * 2 * k, b->act + r0 * 2 * k);
+    if (!into) continue;
+    /* gmx_indirect_run's `into`: predictions at the models' slots, their active bits, the coded bits */
+    const int n_pad = gmx_batch_n_pad(into), mw = gmx_batch_mask_words(into);
+    const uint64_t MT = gmx_batch_max_bits(into);
+    for (uint64_t t = 0; t < n_bits[s]; ++t) {
+      float* mp = gmx_batch_predictions(into) + ((size_t)s * MT + t) * n_pad;
+      uint32_t* mm = gmx_batch_active_mask(into) + ((size_t)s * MT + t) * mw;
+      for (int i = 0; i < k; ++i)
+        for (int h = 0; h < 2; ++h) {
+          const int slot = ib->slot[i][h];
+          mp[slot] = b->pred[(r0 + t) * 2 * k + 2 * i + h];
+          if (b->act[(r0 + t) * 2 * k + 2 * i + h])
+            mm[slot >> 5] |= 1u << (slot & 31);
+          else
+            mm[slot >> 5] &= ~(1u << (slot & 31));
+        }
+      gmx_batch_bits(into)[(size_t)s * MT + t] = b->bits[r0 + t];
+    }
+  }
+  return GMX_OK;
+}
+
+struct gmx_lstm_batch {
+  gmx_lstm* l;
+  uint64_t NB;
+  float *ppm, *pred;
+  uint8_t *bytes, *act;
+  uint32_t* ctx;
+};
+int gmx_lstm_batch_create(gmx_lstm_batch** out, gmx_lstm* l, uint64_t max_bytes) {
+  if (!out || !l || !max_bytes) return GMX_ERR_INVALID;
+  gmx_lstm_batch* b = (gmx_lstm_batch*)calloc(1, sizeof *b);
+  const size_t R = (size_t)l->S * max_bytes;
+  b->l = l;
+  b->NB = max_bytes;
+  b->ppm = (float*)calloc(R * 256, 4);
+  b->bytes = (uint8_t*)calloc(R, 1);
+  b->pred = (float*)calloc(R * 8, 4);
+  b->act = (uint8_t*)calloc(R * 8, 1);
+  b->ctx = (uint32_t*)calloc(R, 4);
+  *out = b;
+  return GMX_OK;
+}
+void gmx_lstm_batch_destroy(gmx_lstm_batch* b) {
+  if (!b) return;
+  free(b->ppm);
+  free(b->bytes);
+  free(b->pred);
+  free(b->act);
+  free(b->ctx);
+  free(b);
+}
+float* gmx_lstm_batch_ppm(gmx_lstm_batch* b) { return b->ppm; }
+uint8_t* gmx_lstm_batch_bytes(gmx_lstm_batch* b) { return b->bytes; }
+const float* gmx_lstm_batch_predictions(gmx_lstm_batch* b) { return b->pred; }
+const uint8_t* gmx_lstm_batch_active(gmx_lstm_batch* b) { return b->act; }
+const uint32_t* gmx_lstm_batch_contexts(gmx_lstm_batch* b) { return b->ctx; }
+int gmx_lstm_batch_upload(gmx_lstm_batch* b, uint64_t n) { return (b && n <= b->NB) ? GMX_OK : GMX_ERR_INVALID; }
+int gmx_lstm_batch_download(gmx_lstm_batch* b, uint64_t n) { return (b && n <= b->NB) ? GMX_OK : GMX_ERR_INVALID; }
+int gmx_lstm_batch_wait(gmx_lstm_batch* b) { return b ? GMX_OK : GMX_ERR_INVALID; }
+int gmx_lstm_run_ragged(gmx_lstm* l, gmx_lstm_batch* b, const uint64_t* n_bytes, int learn) {
+  if (!l || !b || b->l != l || !n_bytes) return GMX_ERR_INVALID;
+  for (int s = 0; s < l->S; ++s) {
+    if (n_bytes[s] > b->NB) return GMX_ERR_INVALID;
+    if (!n_bytes[s]) continue;
+    lstm_stream* st = &l->st[s];
+    const size_t r0 = (size_t)s * b->NB;
+    gmxo_lstm_run(st->l, n_bytes[s], b->ppm + r0 * 256, b->bytes + r0, learn, &st->last_byte, &st->prediction,
+                  &st->context, b->pred + r0 * 8, b->act + r0 * 8, b->ctx + r0);
+  }
+  return GMX_OK;
+}
+int gmx_lstm_feed(gmx_lstm* l, gmx_lstm_batch* b, uint64_t n_bytes, gmx_batch* mb, int slot, int mixer_ctx_col,
+                  gmx_ind_batch* ib, int ind_ctx_col) {
+  if (!l || !b || b->l != l || n_bytes > b->NB) return GMX_ERR_INVALID;
+  for (int s = 0; s < l->S; ++s)
+    for (uint64_t n = 0; n < n_bytes; ++n)
+      for (int k = 0; k < 8; ++k) {
+        const size_t r = (size_t)s * b->NB + n;
+        const uint64_t t = 8 * n + k;
+        if (mb) {
+          const uint64_t MT = gmx_batch_max_bits(mb);
+          const int n_pad = gmx_batch_n_pad(mb), mw = gmx_batch_mask_words(mb), m = gmx_shim_batch_m(mb);
+          gmx_batch_predictions(mb)[((size_t)s * MT + t) * n_pad + slot] = b->pred[r * 8 + k];
+          uint32_t* w = gmx_batch_active_mask(mb) + ((size_t)s * MT + t) * mw + (slot >> 5);
+          *w = b->act[r * 8 + k] ? (*w | 1u << (slot & 31)) : (*w & ~(1u << (slot & 31)));
+          if (mixer_ctx_col >= 0) gmx_batch_contexts(mb)[((size_t)s * MT + t) * m + mixer_ctx_col] = b->ctx[r];
+        }
+        if (ib) ib->ctx[((size_t)s * ib->T + t) * ib->ib->n + ind_ctx_col] = b->ctx[r];
+      }
   return GMX_OK;
 }

@@ -18,27 +18,32 @@ def _skip_unless(*exes):
             pytest.skip(f"oracle/_ref/{exe} not built (needs /root/reference: make -C oracle/ref_build batched)")
 
 
-def test_batched_cli_writes_the_stock_file_and_tables(tmp_path):
+@pytest.mark.parametrize("exe", ["gmix_batched_shim", "gmix_chain_batched_shim"])
+def test_batched_cli_writes_the_stock_file_and_tables(tmp_path, exe):
     """5 000 bytes: 19+ chunks of 2 048 bits and a ragged last one; analysis on (40 bits per row: 1 000 rows whose
-    final-mixer column comes from the returned chunks)."""
-    _skip_unless("gmix_strict", "gmix_batched_shim")
-    src, stock, batched = compress_pair("gmix_strict", "gmix_batched_shim", corpus(5000, 777), tmp_path)
+    final-mixer column comes from the returned chunks).  `chain`: the LSTM and the 41 Indirect models record as
+    well (PPM byte distributions, contexts) and run in batches in front of the mixers, lstm_prediction_context
+    handed on between the batches; the LSTM's and the 30 analysed Indirect predictions' table columns come from
+    the returned chunks too."""
+    _skip_unless("gmix_strict", exe)
+    src, stock, batched = compress_pair("gmix_strict", exe, corpus(5000, 777), tmp_path)
     same_outputs(stock, batched)
     gmix("gmix_strict", "-d", batched / "c", stock / "back", stock)
     assert (stock / "back").read_bytes() == src.read_bytes()
 
 
-@pytest.mark.parametrize("chunk", [8, 72, 4096])
-def test_many_files_ragged_lengths(tmp_path, chunk):
+@pytest.mark.parametrize("exe,chunk", [("gmix_many_shim", 8), ("gmix_many_shim", 72), ("gmix_many_shim", 4096),
+                                       ("gmix_chain_many_shim", 8), ("gmix_chain_many_shim", 1000)])
+def test_many_files_ragged_lengths(tmp_path, exe, chunk):
     """Three Predictors on three threads share one group; files of 1 / 613 / 1 500 bytes end in different rounds
     (a stream that has left must not hold the others up), chunks of one byte up to more than the longest file."""
-    _skip_unless("gmix_strict", "gmix_many_shim")
+    _skip_unless("gmix_strict", exe)
     files = []
     for k, n in enumerate((1, 613, 1500)):
         f = tmp_path / f"f{k}"
         f.write_bytes(corpus(n, 4000 * k))
         files.append(f)
-    st = run_many("gmix_many_shim", files, tmp_path / "out", chunk)
+    st = run_many(exe, files, tmp_path / "out", chunk)
     assert st["failed"] == 0 and st["device_bits"] == 8 * (1 + 613 + 1500)
     for k, f in enumerate(files):
         gmix("gmix_strict", "-c", f, tmp_path / f"ref{k}", tmp_path)
@@ -51,6 +56,8 @@ def test_reference_tester_with_batched_compression(tmp_path):
     gmx::BatchedCompress, the restart / Copy / decode tests through the per-bit path on the bank the batch
     left behind -- the tester itself compares their files with the batched one, and everything it leaves equals
     the stock build's."""
-    _skip_unless("ref_tester_strict", "ref_tester_batched_shim")
-    stock, batched = run_all([("ref_tester_strict", 300), ("ref_tester_batched_shim", 300)], 1200, tmp_path)
+    _skip_unless("ref_tester_strict", "ref_tester_batched_shim", "ref_tester_chain_batched_shim")
+    stock, batched, chain = run_all([("ref_tester_strict", 300), ("ref_tester_batched_shim", 300),
+                                     ("ref_tester_chain_batched_shim", 0)], 1200, tmp_path)
     compare(stock, batched)
+    compare(stock, chain, generation=False)   # (the chain's LSTM bank checkpoints at byte boundaries: no TestGeneration)
