@@ -105,6 +105,27 @@ static int xfer_note_device_use(GmxXfer& x, hipStream_t main) {
   x.dev_rec = true;
   return GMX_OK;
 }
+// Hardware queues.  The runtime maps a process's streams onto FOUR hardware queues per priority level, round robin,
+// and work on one queue runs in order whatever streams it came from.  The chain LSTM -> Indirect models -> mixers keeps
+// three compute streams busy at once (the LSTM of chunk k+1 beside the mixers of chunk k) plus their transfer
+// streams: on one level those ten streams share four queues, and an LSTM launch or an upload sits behind a 3 ms mixer
+// kernel it has nothing to do with (measured: 6.2 us per bit for one compressor instead of 4.0; GPU_MAX_HW_QUEUES=8
+// hid it, which is how it was found).  So every bank type lives on a priority level of its own -- the mixers normal,
+// the Indirect models least, the LSTM (the longest stage) greatest -- and a bank's transfer streams follow its compute
+// stream's level: at most four streams per level.
+static hipError_t bank_stream_create(hipStream_t* out, int level /* 0 normal, 1 least, 2 greatest */) {
+  int least = 0, greatest = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (e != hipSuccess) return e;
+  const int mid = (least + greatest) / 2;
+  return hipStreamCreateWithPriority(out, hipStreamNonBlocking, level == 1 ? least : level == 2 ? greatest : mid);
+}
+static hipError_t sibling_stream_create(hipStream_t* out, hipStream_t main) {
+  int p = 0;
+  hipError_t e = hipStreamGetPriority(main, &p);
+  if (e != hipSuccess) return e;
+  return hipStreamCreateWithPriority(out, hipStreamNonBlocking, p);
+}
 // The stream an upload of `bytes` runs on: one of its own (created on demand) behind the last
 // device-side use of the batch, or the bank's stream for small ones.
 static int xfer_begin_upload(GmxXfer& x, hipStream_t main, hipStream_t* own, size_t bytes, hipStream_t* use) {
@@ -112,7 +133,7 @@ static int xfer_begin_upload(GmxXfer& x, hipStream_t main, hipStream_t* own, siz
     *use = main;
     return GMX_OK;
   }
-  if (!*own) HIPCHK(hipStreamCreateWithFlags(own, hipStreamNonBlocking));
+  if (!*own) HIPCHK(sibling_stream_create(own, main));
   *use = *own;
   if (x.dev_rec) HIPCHK(hipStreamWaitEvent(*use, x.ev_dev, 0));
   return GMX_OK;
@@ -128,7 +149,7 @@ static int xfer_begin_download(GmxXfer& x, hipStream_t main, hipStream_t* own, s
     *use = main;
     return GMX_OK;
   }
-  if (!*own) HIPCHK(hipStreamCreateWithFlags(own, hipStreamNonBlocking));
+  if (!*own) HIPCHK(sibling_stream_create(own, main));
   *use = *own;
   int rc = xfer_note_device_use(x, main);
   if (rc) return rc;
@@ -469,7 +490,7 @@ extern "C" int gmx_group_create(gmx_group** out, const gmx_topology* topo, int n
       return e_ == hipErrorOutOfMemory ? GMX_ERR_NOMEM : r_; \
     }                                              \
   } while (0)
-  GCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+  GCHK(bank_stream_create(&g->stream, 0));
   GCHK(hipEventCreate(&g->ev0));
   GCHK(hipEventCreate(&g->ev1));
   GCHK(hipMalloc((void**)&g->topo_dev, sizeof(GmxTopoDev)));
@@ -695,7 +716,7 @@ static int prepare_decay(gmx_group* g, int s0, int ns, uint64_t T, int learn, gm
     HIPCHK(hipEventCreateWithFlags(&d.done, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&d.ready, hipEventDisableTiming));
   }
-  if (!g->copy_stream) HIPCHK(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
+  if (!g->copy_stream) HIPCHK(sibling_stream_create(&g->copy_stream, g->stream));
   // Streams at the same bit count share a row; with many different counts the device makes the
   // table (see gmx_decay_kernel), else the host's libm loop is shorter than the detour.
   bool on_device = false;
@@ -1313,7 +1334,7 @@ extern "C" int gmx_debug_decay_table(gmx_group* g, const uint64_t* steps0, int U
                                      uint32_t* n_unsettled) {
   if (!g || !steps0 || U < 1 || T < 1 || !out) return GMX_ERR_INVALID;
   HIPCHK(hipSetDevice(g->device));
-  if (!g->copy_stream) HIPCHK(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
+  if (!g->copy_stream) HIPCHK(sibling_stream_create(&g->copy_stream, g->stream));
   gmx_group::DecaySlot tmp;
   std::map<uint64_t, uint32_t> uniq;
   std::vector<uint32_t> row(U);
@@ -1435,6 +1456,8 @@ static int stream_with_cu_mask(hipStream_t* st, const uint32_t* mask, int n_word
   hipStream_t fresh = nullptr;
   if (n_words > 0)
     HIPCHK(hipExtStreamCreateWithCUMask(&fresh, (uint32_t)n_words, mask));
+  else if (*st)
+    HIPCHK(sibling_stream_create(&fresh, *st));  // (all CUs again: back on the bank's own priority level)
   else
     HIPCHK(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
   if (*st) {

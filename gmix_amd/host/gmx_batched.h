@@ -315,6 +315,8 @@ struct BatchedStats {
   uint64_t launches = 0;       // chunks of all streams queued on the device
   uint64_t bits = 0;           // bits of all streams mixed there
   int pinned_threads = 0;      // threads kept on the cores of the device's NUMA node
+  double submit_seconds = 0;   // host time spent queueing chunks on the device ...
+  double wait_seconds = 0;     // ... and waiting for the chunk before (all streams stand still meanwhile)
 };
 
 // runner_utils::RunCompression (runner-utils.cpp:88-121) for every job at once: a Predictor and a thread per
@@ -393,6 +395,8 @@ inline int BatchedCompressFiles(std::vector<BatchedJob>& jobs, const BatchedOpti
     stats->launches = pool.rounds();
     stats->bits = pool.bits_submitted();
     stats->pinned_threads = pinned.load();
+    stats->submit_seconds = pool.submit_seconds();
+    stats->wait_seconds = pool.wait_seconds();
   }
   return failed;
 }

@@ -43,6 +43,7 @@
 #include <cmath>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -167,6 +168,10 @@ class MixerPool {
   uint64_t chunk_bits() const { return T_; }
   uint64_t bits_submitted() const { return bits_submitted_; }  // bits of all streams queued on the device so far
   uint64_t rounds() const { return round_; }                   // chunks (of all streams together) handed in
+  // host time the submitting stream spent queueing chunks / waiting for the chunk before (the device's share of
+  // the wall time when it, not the hosts' feature models, sets the pace)
+  double submit_seconds() const { return submit_seconds_; }
+  double wait_seconds() const { return wait_seconds_; }
 
   enum Parts { kMixers = 1, kIndirect = 2, kLstm = 4 };
 
@@ -374,6 +379,7 @@ class MixerPool {
   }
   // Every stream has handed in its chunk: queue it behind the chunk before, wait for THAT one.  mu_ held.
   void Lead() {
+    const auto lead_t0 = std::chrono::steady_clock::now();
     const int c = cur_;
     uint64_t maxn = 0, sum = 0;
     for (int i = 0; i < S_; ++i) {
@@ -413,6 +419,7 @@ class MixerPool {
     n_in_[c] = n_cur_;
     std::fill(n_cur_.begin(), n_cur_.end(), 0);
     const int other = c ^ 1;
+    const auto lead_t1 = std::chrono::steady_clock::now();
     if (rc == GMX_OK && busy_[other]) {
       busy_[other] = false;
       GMX_POOL_STEP(gmx_batch_wait(ring_[other]));
@@ -421,6 +428,8 @@ class MixerPool {
     }
 #undef GMX_POOL_STEP
     if (rc) Fail(what, rc);
+    submit_seconds_ += std::chrono::duration<double>(lead_t1 - lead_t0).count();
+    wait_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - lead_t1).count();
     cur_ = other;
     arrived_ = 0;
     ++round_;
@@ -489,6 +498,7 @@ class MixerPool {
   int cur_ = 0, parts_ = 0, lstm_slot_ = -1, mixer_ctx_col_ = -1, ind_ctx_col_ = -1;
   bool models_back_ = false;
   uint64_t T_ = 0, round_ = 0, bits_submitted_ = 0;
+  double submit_seconds_ = 0, wait_seconds_ = 0;
   int n_pad_ = 0, mask_words_ = 0, M_ = 0, K_ = 0;
   int participants_ = 0, arrived_ = 0;
   std::vector<uint64_t> n_cur_, n_in_[2], n_bytes_;

@@ -56,9 +56,11 @@ int main(int argc, char** argv) {
   const int failed = gmx::BatchedCompressFiles(jobs, opt, &st);
   unsigned long long in_bytes = 0, out_bytes = 0;
   printf("{\"files\": %zu, \"failed\": %d, \"chunk_bits\": %llu, \"wall_seconds\": %.6f, \"build_seconds\": %.3f, "
-         "\"launches\": %llu, \"device_bits\": %llu, \"pinned_threads\": %d, \"jobs\": [",
+         "\"launches\": %llu, \"device_bits\": %llu, \"pinned_threads\": %d, \"submit_seconds\": %.4f, "
+         "\"wait_seconds\": %.4f, \"jobs\": [",
          jobs.size(), failed, (unsigned long long)opt.chunk_bits, st.wall_seconds, st.build_seconds,
-         (unsigned long long)st.launches, (unsigned long long)st.bits, st.pinned_threads);
+         (unsigned long long)st.launches, (unsigned long long)st.bits, st.pinned_threads, st.submit_seconds,
+         st.wait_seconds);
   for (size_t k = 0; k < jobs.size(); ++k) {
     printf("%s{\"in\": %llu, \"out\": %llu, \"status\": %d, \"seconds\": %.6f}", k ? ", " : "", jobs[k].input_bytes,
            jobs[k].output_bytes, jobs[k].status, jobs[k].seconds);

@@ -13,10 +13,10 @@ echo "host: $(grep -m1 'model name' /proc/cpuinfo | cut -d: -f2), $(nproc) cpus 
 for S in $LIST; do
   rm -rf $W/f; mkdir -p $W/f
   for i in $(seq 0 $((S-1))); do tail -c +$((i*1531+1)) $W/corpus | head -c $N > $W/f/$i; done
-  for mode in "" "--no-pin"; do
-    $REF/gmix_many -T 2048 $mode $W/out $W/f/* > $W/j.json
-    python3 -c "import json;j=json.load(open('$W/j.json'));print('gmix_many S=%d %s: %.3g bits/s aggregate, %.2f s wall, %.1f us per bit per stream, build %.1f s, pinned %d' % (j['files'],'$mode',j['bits_per_second'],j['wall_seconds'],j['wall_seconds']*1e6/(8*$N),j['build_seconds'],j['pinned_threads']))"
-  done
+  for exe in gmix_many gmix_chain_many; do for mode in "" "--no-pin"; do
+    $REF/$exe -T ${CHUNK:-2048} $mode $W/out $W/f/* > $W/j.json
+    python3 -c "import json;j=json.load(open('$W/j.json'));print('$exe S=%d %s: %.3g bits/s aggregate, %.2f s wall, %.2f us per bit per stream, build %.1f s, pinned %d' % (j['files'],'$mode',j['bits_per_second'],j['wall_seconds'],j['wall_seconds']*1e6/(8*$N),j['build_seconds'],j['pinned_threads']))"
+  done; done
   s=$(date +%s.%N)
   for i in $(seq 0 $((S-1))); do ( mkdir -p $W/s$i; cd $W/s$i; $REF/gmix_strict -c $W/f/$i out >/dev/null 2>&1 ) & done; wait
   e=$(date +%s.%N)

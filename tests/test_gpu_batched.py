@@ -14,15 +14,27 @@ from dropin_common import compare, run_pair
 pytestmark = pytest.mark.gpu
 
 
-def test_batched_compress_100k_equals_stock_and_round_trips(gpu, tmp_path):
+@pytest.mark.parametrize("exe", ["gmix_batched", "gmix_chain_batched"])
+def test_batched_compress_100k_equals_stock_and_round_trips(gpu, tmp_path, exe):
     """`gmix -c` of 100 000 bytes of text: 391 chunks of 2 048 bits through the two-batch ring.  Same compressed
     bytes as the stock build, same analysis tables (1 000 rows whose final-mixer entropy is computed from the
-    returned chunks), and the STOCK build's `gmix -d` restores the input from the run-ahead compressor's file."""
-    need("gmix_strict", "gmix_batched")
-    src, stock, batched = compress_pair("gmix_strict", "gmix_batched", corpus(100000), tmp_path)
+    returned chunks), and the STOCK build's `gmix -d` restores the input from the run-ahead compressor's file.
+    gmix_chain_batched: LSTM -> 41 Indirect models -> 33 mixers on the device, each chunk a chain of three batched
+    kernels with lstm_prediction_context and 83 of the mixers' 90 inputs handed on inside HBM; the host runs PPMd,
+    the match models, the context hashes and the coder; the LSTM's and the Indirect models' analysis columns come
+    from the device too."""
+    need("gmix_strict", exe)
+    src, stock, batched = compress_pair("gmix_strict", exe, corpus(100000), tmp_path)
     same_outputs(stock, batched)
     gmix("gmix_strict", "-d", batched / "c", stock / "back", stock)
     assert (stock / "back").read_bytes() == src.read_bytes()
+
+
+def test_reference_tester_chain_with_batched_compression_equals_stock(gpu, tmp_path):
+    """The same with the whole device chain (no TestGeneration: the LSTM bank checkpoints at byte boundaries)."""
+    need("ref_tester_strict", "ref_tester_chain_batched")
+    da, db = run_pair("ref_tester_strict", "ref_tester_chain_batched", 6000, 0, tmp_path)
+    compare(da, db, generation=False)
 
 
 def test_reference_tester_with_batched_compression_equals_stock(gpu, tmp_path):
@@ -34,17 +46,19 @@ def test_reference_tester_with_batched_compression_equals_stock(gpu, tmp_path):
     compare(da, db)
 
 
-def test_64_files_side_by_side_equal_stock(gpu, tmp_path):
-    """64 Predictors on 64 host threads, their mixers 64 streams of ONE gmx_group, one launch per 2 048-bit chunk for
-    all of them; files of 30 000 .. 36 300 bytes starting at different places of the corpus, so they end in
-    different rounds.  Every output is the stock build's `gmix -c` of the same file."""
-    need("gmix_strict", "gmix_many")
+@pytest.mark.parametrize("exe", ["gmix_many", "gmix_chain_many"])
+def test_64_files_side_by_side_equal_stock(gpu, tmp_path, exe):
+    """64 Predictors on 64 host threads, their mixers 64 streams of ONE gmx_group (gmix_chain_many: and their LSTMs
+    and Indirect models 64 streams of one gmx_lstm / gmx_indirect), one launch per bank and 2 048-bit chunk for all of
+    them; files of 30 000 .. 36 300 bytes starting at different places of the corpus, so they end in different
+    rounds.  Every output is the stock build's `gmix -c` of the same file."""
+    need("gmix_strict", exe)
     files = []
     for k in range(64):
         f = tmp_path / f"f{k}"
         f.write_bytes(corpus(30000 + 100 * k, 1531 * k))
         files.append(f)
-    st = run_many("gmix_many", files, tmp_path / "out", 2048)
+    st = run_many(exe, files, tmp_path / "out", 2048)
     assert st["failed"] == 0 and st["files"] == 64
     assert st["device_bits"] == 8 * sum(30000 + 100 * k for k in range(64))
 
@@ -58,21 +72,22 @@ def test_64_files_side_by_side_equal_stock(gpu, tmp_path):
         refs = list(ex.map(stock, range(64)))
     for k in range(64):
         assert refs[k] == (tmp_path / "out" / f"{k}.gmix").read_bytes(), f"file {k} differs from gmix_strict -c"
-    print(f"64 files: {st['bits_per_second']:.3g} bits/s aggregate, {st['wall_seconds']:.2f} s, "
+    print(f"{exe}, 64 files: {st['bits_per_second']:.3g} bits/s aggregate, {st['wall_seconds']:.2f} s, "
           f"{st['launches']} launches, {st['pinned_threads']} threads pinned")
 
 
-@pytest.mark.parametrize("chunk", [8, 1000])
-def test_small_chunks_and_ragged_ends(gpu, tmp_path, chunk):
+@pytest.mark.parametrize("exe,chunk", [("gmix_many", 8), ("gmix_many", 1000), ("gmix_chain_many", 8),
+                                       ("gmix_chain_many", 1000)])
+def test_small_chunks_and_ragged_ends(gpu, tmp_path, exe, chunk):
     """Chunks of one byte (every launch is a ragged one at the end) and of 1 000 bits for files of 1 .. 2 000 bytes."""
-    need("gmix_strict", "gmix_many")
+    need("gmix_strict", exe)
     sizes = (1, 300, 2000, 2000, 777)
     files = []
     for k, n in enumerate(sizes):
         f = tmp_path / f"f{k}"
         f.write_bytes(corpus(n, 5000 * k))
         files.append(f)
-    st = run_many("gmix_many", files, tmp_path / "out", chunk)
+    st = run_many(exe, files, tmp_path / "out", chunk)
     assert st["failed"] == 0 and st["device_bits"] == 8 * sum(sizes)
     for k, f in enumerate(files):
         gmix("gmix_strict", "-c", f, tmp_path / f"ref{k}", tmp_path)
