@@ -18,6 +18,9 @@ way (barrier, K steps, max over ranks) with its own roofline and one-core refere
   stock_S1     ONE stream of the reference's shape: what a single compressor sees
   indirect     (one GPU) the 41 Indirect models in front of the mixers, 256 streams -- scripts/bench_indirect.py
   lstm         (one GPU) the LSTM byte model, 1024 streams, bytes/s -- scripts/bench_lstm.py
+  e2e_S1 / e2e_S1_mixers / e2e_S64   (one GPU) whole files through the run-ahead compressor: the reference's feature
+               models and coder on the host cores, LSTM + Indirect models + mixers (or the mixers alone) on the device in
+               double-buffered batches; 1 file and 64 files side by side -- scripts/bench_e2e.py
 (--no-also leaves them out; --config X makes X the headline workload for profiling.)
 
 N > 1: one rank per GPU over RCCL.  Under torch.distributed.run the ranks come from the environment;
@@ -376,7 +379,12 @@ def main():
         if world == 1:
             # the producers in front of the mixers, timed by their own scripts' code:
             # the 41 Indirect models (bits/s) and the LSTM byte model (bytes/s), each with roofline + cpu_baseline
-            for name, script, kw in (("indirect", "bench_indirect.py", {}), ("lstm", "bench_lstm.py", {})):
+            # ... and whole files end to end: the reference's feature models and coder on the host running ahead of
+            # the device-side models (scripts/bench_e2e.py; every output compared with the stock build's)
+            for name, script, kw in (("indirect", "bench_indirect.py", {}), ("lstm", "bench_lstm.py", {}),
+                                     ("e2e_S1", "bench_e2e.py", {"streams": 1, "variant": "chain"}),
+                                     ("e2e_S1_mixers", "bench_e2e.py", {"streams": 1, "variant": "mixers"}),
+                                     ("e2e_S64", "bench_e2e.py", {"streams": 64, "variant": "chain"})):
                 try:
                     also[name] = aux_bench(script).measure(**kw)
                     if args.no_cpu_baseline:

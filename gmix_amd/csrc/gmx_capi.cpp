@@ -216,6 +216,7 @@ struct gmx_group {
   std::vector<gmx_batch*> batches; // live batches; orphaned (b->g = nullptr) when the group dies
   std::vector<struct GmxSession*> sessions;  // per stream, lazily: persistent per-bit kernels
   std::vector<struct gmx_lockstep*> locksteps;  // live lock-step objects; orphaned (ls->g = nullptr) when the group dies
+  bool banks_in_use_by_dead_kernel = false;  // a persistent wave that stopped answering may still hold them: never freed
   bool use_sessions = true;        // tests: per-bit calls as two launches instead of a session
   bool mailbox_on_device = true;   // tests: false keeps the sessions' command blocks in pinned host memory
   bool force_general = false;      // tests: route everything through the general kernel
@@ -279,7 +280,7 @@ struct gmx_lockstep {
 
 // per-bit sessions (gmx_session.inc); sessions_close also stops the persistent lock-step waves of the group
 static int sessions_close(gmx_group* g, bool keep_forward);
-static int locksteps_stop(gmx_group* g, gmx_lockstep* except);
+static int locksteps_stop(gmx_group* g, gmx_lockstep* except, bool keep_forward);
 static void sessions_free(gmx_group* g);
 
 extern "C" const char* gmx_strerror(int status) {
@@ -524,9 +525,13 @@ extern "C" void gmx_group_destroy(gmx_group* g) {
   g->locksteps.clear();
   for (gmx_batch* b : g->batches) b->g = nullptr;
   g->batches.clear();
-  if (g->banks) (void)hipFree(g->banks);
-  if (g->latch_out) (void)hipFree(g->latch_out);
-  if (g->topo_dev) (void)hipFree(g->topo_dev);
+  // (a persistent wave that stopped answering and is still resident reads the topology and writes rows and latch:
+  // leaked rather than freed under a running kernel)
+  if (!g->banks_in_use_by_dead_kernel) {
+    if (g->banks) (void)hipFree(g->banks);
+    if (g->latch_out) (void)hipFree(g->latch_out);
+    if (g->topo_dev) (void)hipFree(g->topo_dev);
+  }
   for (auto& d : g->decay) {
     if (d.st_dev) (void)hipFree(d.st_dev);
     if (d.st_host) (void)hipHostFree(d.st_host);
@@ -1512,6 +1517,9 @@ extern "C" int gmx_chain_forward(gmx_indirect* ib, gmx_group* g, int stream, con
   if (n_active > 0 && !active_models) return GMX_ERR_INVALID;
   const GmxTopoDev& t = g->topo;
   const int K = ib->dev.k;
+  if (n_active > t.n) return GMX_ERR_INVALID;
+  for (int i = 0; i < n_active; ++i)  // before either bank has moved: a bad index must not leave the Indirect models mid-bit
+    if (active_models[i] < 0 || active_models[i] >= t.n) return GMX_ERR_INVALID;
   uint32_t own[GMX_MAX_INPUTS / 32] = {0};  // the active-mask bits of the Indirect models' slots
   for (int i = 0; i < K; ++i) {
     const int a = ib->dev.m[i].slot_a, b = ib->dev.m[i].slot_b;
@@ -1567,27 +1575,30 @@ extern "C" int gmx_chain_forward(gmx_indirect* ib, gmx_group* g, int stream, con
     }
     if (rc != GMX_ERR_STATE) return rc;  // GMX_ERR_STATE: no session slot for the mixers, the two calls instead
   }
-  // the two calls, the host in between
+  // the two calls, the host in between (fixed-size arrays: no allocation on a per-bit path)
   int rc = gmx_indirect_forward(ib, stream, ind_contexts, bit_context, ipd, iad);
   if (rc) return rc;
-  std::vector<float> pr(predictions, predictions + t.n);
-  std::vector<int32_t> act;
-  for (int i = 0; i < n_active; ++i) {
-    const int idx = active_models[i];
-    if (idx < 0 || idx >= t.n) return GMX_ERR_INVALID;
-    if (!((own[idx >> 5] >> (idx & 31)) & 1u)) act.push_back(idx);
+  float pr[GMX_MAX_INPUTS];
+  int32_t act[GMX_MAX_INPUTS];
+  int na = 0;
+  memcpy(pr, predictions, (size_t)t.n * sizeof(float));
+  uint32_t on[GMX_MAX_INPUTS / 32] = {0};
+  if (n_active < 0) {
+    for (int idx = 0; idx < t.n; ++idx) on[idx >> 5] |= 1u << (idx & 31);
+  } else {
+    for (int i = 0; i < n_active; ++i) on[active_models[i] >> 5] |= 1u << (active_models[i] & 31);
   }
-  if (n_active < 0)
-    for (int idx = 0; idx < t.n; ++idx)
-      if (!((own[idx >> 5] >> (idx & 31)) & 1u)) act.push_back(idx);
+  for (int w = 0; w < GMX_MAX_INPUTS / 32; ++w) on[w] &= ~own[w];
   for (int i = 0; i < K; ++i) {
     const int sl[2] = {ib->dev.m[i].slot_a, ib->dev.m[i].slot_b};
     for (int h = 0; h < 2; ++h) {
       pr[sl[h]] = ipd[2 * i + h];
-      if (iad[2 * i + h]) act.push_back(sl[h]);
+      if (iad[2 * i + h]) on[sl[h] >> 5] |= 1u << (sl[h] & 31);
     }
   }
-  rc = gmx_bank_forward(g, stream, pr.data(), act.data(), (int)act.size(), contexts, p_final, out_all);
+  for (int idx = 0; idx < t.n; ++idx)  // ascending, like ShortTermMemory::active_models
+    if ((on[idx >> 5] >> (idx & 31)) & 1u) act[na++] = idx;
+  rc = gmx_bank_forward(g, stream, pr, act, na, contexts, p_final, out_all);
   if (rc) return rc;
   if (ind_predictions) memcpy(ind_predictions, ipd, n2 * 4);
   if (ind_active) memcpy(ind_active, iad, n2);

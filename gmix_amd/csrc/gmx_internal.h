@@ -90,6 +90,8 @@ struct GmxRunArgs {
 #define GMX_MB_STOP 4u
 #define GMX_MB_LEARN0_FWD 5u  // learn (bit 0) of the previous forward, then forward of the slot's payload
 #define GMX_MB_LEARN1_FWD 6u
+#define GMX_MB_STOP_KEEP 7u   // lock-step waves only: leave like GMX_MB_STOP, but a forward nobody has learned from yet
+                              // is redone by the next instance from the block's own copy (as after an idle exit)
 #define GMX_MB_CMD_MASK 7u
 #define GMX_MB_SLOT_SHIFT 3
 #define GMX_MB_SEQ_SHIFT 4
