@@ -367,12 +367,17 @@ int gmx_lstm_perceive(gmx_lstm* l, int stream, int byte);
  * LstmModel::WriteToDisk / ReadFromDisk (lstm-model.cpp:62-76) with Lstm::, LstmLayer:: and 3 x
  * NeuronLayer::WriteToDisk behind it (lstm.cpp:124-158, lstm-layer.cpp:356-394, :62-122; 1 458 256
  * bytes); `long` = the LSTM section of LongTermMemory::WriteToDisk / ReadFromDisk
- * (long-term-memory.cpp:57-67, :151-160; 5 560 200 bytes).  Both buffers NULL: sizes only.  A bank
- * stands at a byte boundary (GMX_ERR_STATE between gmx_lstm_forward and gmx_lstm_perceive), so
- * top_/mid_/bot_ are written as the eighth LstmModel::Predict of the last coded byte leaves them,
- * and import refuses (GMX_ERR_FORMAT) a checkpoint the reference took inside a byte.  After an
- * import the bank's remembered last byte is the newest entry of input_history_; a stream that
- * did not learn from its last byte passes it explicitly (gmx_lstm_forward).
+ * (long-term-memory.cpp:57-67, :151-160; 5 560 200 bytes).  Both buffers NULL: sizes only.  Where a byte has
+ * ended top_/mid_/bot_ are written as the eighth LstmModel::Predict of the last coded byte leaves them.  Between
+ * gmx_lstm_forward and gmx_lstm_perceive -- LstmModel::WriteToDisk works at any bit, and the reference's
+ * TestGeneration checkpoints after a Predict whose byte is never perceived (tester.cpp:284, :312) -- the network's
+ * state is what the forward left, and the range state, which the caller advances on the host from there
+ * (lstm-model.cpp:34-48), is written as that forward's own Predict leaves it (255 / 127 / 0): a caller further into
+ * the byte puts its own top_/mid_/bot_ into the first 12 bytes.  import takes either kind; a file does not say
+ * whether its newest forward has been perceived (the reference keeps no such flag), so after an import of anything
+ * but an untouched model both gmx_lstm_perceive and gmx_lstm_forward are accepted next.  After an import the
+ * bank's remembered last byte is the newest perceived entry of input_history_; a stream that did not learn from its
+ * last byte passes it explicitly (gmx_lstm_forward).
  * copy = LstmModel::Copy (lstm-model.cpp:78-85) + the LSTM share of LongTermMemory::Copy
  * (long-term-memory.cpp:216-219); memory_usage = LstmModel::GetMemoryUsage (lstm-model.cpp:87-101). */
 int gmx_lstm_export(gmx_lstm* l, int stream, void* long_buf, size_t* long_bytes, void* short_buf,

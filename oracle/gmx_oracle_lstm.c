@@ -281,6 +281,32 @@ static float logit(float p) {
   return logf(p / (1 - p));
 }
 
+/* The bit-level half of LstmModel::Predict alone (lstm-model.cpp:34-48), for callers that hold the byte distribution
+ * themselves (the per-byte device surface hands out probs_; the range is the host's): advances top/mid/bot by new_bit
+ * (first != 0: a new byte, the full range) and returns what SetPrediction would do -- 1 active, 0 stored but silent
+ * or nothing stored (*prediction untouched when denom == 0). */
+int gmxo_lstm_bit_from_probs(const float* probs, int first, int new_bit, int* top, int* mid, int* bot, float* prediction) {
+  if (first) {
+    *top = 255;
+    *bot = 0;
+  } else if (new_bit) {
+    *bot = *mid + 1;
+  } else {
+    *top = *mid;
+  }
+  *mid = *bot + ((*top - *bot) / 2);
+  float num = 0.0f;
+  for (int i = *mid + 1; i <= *top; ++i) num += probs[i];
+  float denom = num;
+  for (int i = *bot; i <= *mid; ++i) denom += probs[i];
+  if (denom != 0) {
+    float p = num / denom;
+    *prediction = logit(p);
+    return p == 0.5 ? 0 : 1;
+  }
+  return 0;
+}
+
 /* LstmModel::Predict (lstm-model.cpp:17-49).  recent_bits / last_byte / new_bit as the context
  * models left them in ShortTermMemory.  *prediction keeps its old value when the model stays
  * silent (denom == 0); returns 1 if SetPrediction marked it active, else 0;
@@ -442,8 +468,15 @@ uint64_t gmxo_lstm_weights_hash(const gmxo_lstm* l, int with_output_layer) {
 #include "gmx_lstm_synth.h"
 
 /* The loop of oracle/ref_build/ref_lstm_harness.cpp around the restated model. */
+uint64_t gmxo_lstm_run_synth2(gmxo_lstm* l, uint64_t n_bytes, uint64_t seed, uint32_t mask, uint64_t dump,
+                              uint64_t nolearn_from, float* pred_out, uint8_t* act_out, uint32_t* ctx_out);
 uint64_t gmxo_lstm_run_synth(gmxo_lstm* l, uint64_t n_bytes, uint64_t seed, uint32_t mask, uint64_t dump,
                              float* pred_out, uint8_t* act_out, uint32_t* ctx_out) {
+  return gmxo_lstm_run_synth2(l, n_bytes, seed, mask, dump, ~0ull, pred_out, act_out, ctx_out);
+}
+/* ... from byte nolearn_from on without LstmModel::Learn (the harness's --nolearn-from: generation) */
+uint64_t gmxo_lstm_run_synth2(gmxo_lstm* l, uint64_t n_bytes, uint64_t seed, uint32_t mask, uint64_t dump,
+                              uint64_t nolearn_from, float* pred_out, uint8_t* act_out, uint32_t* ctx_out) {
   gmx_lstm_synth g;
   gmx_lstm_synth_init(&g, seed, mask);
   float ppm[256], cur_ppm[256];
@@ -466,7 +499,7 @@ uint64_t gmxo_lstm_run_synth(gmxo_lstm* l, uint64_t n_bytes, uint64_t seed, uint
         if (k == 0) ctx_out[n] = context;
       }
       new_bit = (int)((byte >> (7 - k)) & 1u);
-      gmxo_lstm_model_learn(l, recent_bits, new_bit);
+      if (n < nolearn_from) gmxo_lstm_model_learn(l, recent_bits, new_bit);
       recent_bits += recent_bits + new_bit;
       if (recent_bits >= 256) {
         last_byte = (uint32_t)(recent_bits - 256);

@@ -343,6 +343,9 @@ def _lstm_lib():
         L.gmxo_lstm_run_synth.restype = C.c_uint64
         L.gmxo_lstm_run_synth.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p,
                                           C.c_void_p, C.c_void_p]
+        L.gmxo_lstm_run_synth2.restype = C.c_uint64
+        L.gmxo_lstm_run_synth2.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]
         L.gmxo_srand.argtypes = [C.c_uint]
         L.gmxo_lstm_synth_fill.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
         L.gmxo_lstm_run.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint32),
@@ -407,6 +410,23 @@ class LstmModel:
         assert self.L.gmxo_lstm_import_long(self.h, _p(a), len(a)) == 0
         assert self.L.gmxo_lstm_import_short(self.h, _p(b), len(b)) == 0
 
+    def bits_from_probs(self, probs, byte):
+        """The 8 bit predictions LstmModel::Predict derives from a byte distribution while `byte` is coded
+        (lstm-model.cpp:34-48): (prediction[8], active[8], (top, mid, bot) after the eighth)."""
+        L = self.L
+        L.gmxo_lstm_bit_from_probs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        probs = np.ascontiguousarray(probs, np.float32)
+        top, mid, bot = C.c_int(255), C.c_int(127), C.c_int(0)
+        pr = C.c_float(self._pr.value)
+        out, act = np.zeros(8, np.float32), np.zeros(8, np.uint8)
+        for k in range(8):
+            new_bit = (int(byte) >> (8 - k)) & 1 if k else 0
+            act[k] = L.gmxo_lstm_bit_from_probs(_p(probs), int(k == 0), new_bit, C.byref(top), C.byref(mid), C.byref(bot),
+                                                C.byref(pr))
+            out[k] = pr.value
+        self._pr.value = pr.value
+        return out, act, (top.value, mid.value, bot.value)
+
     def predict_byte(self, ppm, last_byte):
         x = np.ascontiguousarray(ppm, np.float32)
         probs = np.zeros(256, np.float32)
@@ -431,13 +451,14 @@ class LstmModel:
                              C.byref(self._cx), _p(pred), _p(act), _p(ctx))
         return pred, act, ctx
 
-    def run_synth(self, n_bytes, seed=0, mask=255, dump=0):
+    def run_synth(self, n_bytes, seed=0, mask=255, dump=0, nolearn_from=None):
         """Drive the model with oracle/gmx_lstm_synth.h like the reference harness does; returns
         (fnv over all bits, predictions[dump,8], active[dump,8], context[dump])."""
         pred = np.zeros((dump, 8), np.float32)
         act = np.zeros((dump, 8), np.uint8)
         ctx = np.zeros(dump, np.uint32)
-        h = self.L.gmxo_lstm_run_synth(self.h, n_bytes, seed, mask, dump, _p(pred), _p(act), _p(ctx))
+        h = self.L.gmxo_lstm_run_synth2(self.h, n_bytes, seed, mask, dump,
+                                        (1 << 64) - 1 if nolearn_from is None else nolearn_from, _p(pred), _p(act), _p(ctx))
         return int(h), pred, act, ctx
 
 

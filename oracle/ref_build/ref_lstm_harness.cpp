@@ -6,7 +6,9 @@
 // last_byte), ModPPMD's ppm_predictions refreshed at byte boundaries, LstmModel::Predict, new_bit,
 // LstmModel::Learn.  Input: oracle/gmx_lstm_synth.h.  Ground truth for oracle/gmx_oracle_lstm.c.
 //
-// usage: ref_lstm_harness --bytes N [--dump D] [--seed S] [--mask M] --out file
+// usage: ref_lstm_harness --bytes N [--dump D] [--seed S] [--mask M] [--nolearn-from N0] --out file
+//   --nolearn-from N0: from byte N0 on LstmModel::Learn is not called (generation, runner-utils.cpp:199-209: Predict and
+//   Perceive only) -- Lstm::Predict then runs on output layers and histories no Perceive has refreshed
 // dump format "GMXL": u32 magic, N, D; u64 fnv of the initial gate weights;
 //   D x { float probs[256]; u32 lstm_prediction_context; 8 x { float prediction; u8 active } };
 //   u64 fnv over all bytes of (8 predictions, 8 active flags, context); u64 fnv of the final
@@ -36,7 +38,7 @@ static uint64_t Fnv(uint64_t h, const void* p, size_t n) {
 }
 
 int main(int argc, char** argv) {
-  uint64_t N = 300, dump = 0, seed = 0;
+  uint64_t N = 300, dump = 0, seed = 0, nolearn_from = ~0ull;
   uint32_t mask = 255;
   std::string out_path;
   for (int i = 1; i < argc; ++i) {
@@ -46,6 +48,7 @@ int main(int argc, char** argv) {
     else if (a == "--dump") dump = strtoull(next().c_str(), 0, 0);
     else if (a == "--seed") seed = strtoull(next().c_str(), 0, 0);
     else if (a == "--mask") mask = (uint32_t)strtoul(next().c_str(), 0, 0);
+    else if (a == "--nolearn-from") nolearn_from = strtoull(next().c_str(), 0, 0);
     else if (a == "--out") out_path = next();
     else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
   }
@@ -99,7 +102,7 @@ int main(int argc, char** argv) {
         if (k == 0) Put(out, (uint32_t)stm.lstm_prediction_context);
       }
       stm.new_bit = (byte >> (7 - k)) & 1;
-      model.Learn(stm, ltm);
+      if (n < nolearn_from) model.Learn(stm, ltm);
       // what BasicContexts::Predict does at the start of the next bit (basic-contexts.cpp:27-33)
       stm.recent_bits += stm.recent_bits + stm.new_bit;
       if (stm.recent_bits >= 256) {

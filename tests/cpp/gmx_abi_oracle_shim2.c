@@ -149,7 +149,13 @@ int gmx_lstm_create(gmx_lstm** out, int n_streams, int device) {
   gmx_lstm* l = (gmx_lstm*)calloc(1, sizeof *l);
   l->S = n_streams;
   l->st = (lstm_stream*)calloc((size_t)n_streams, sizeof(lstm_stream));
+  /* gmxo_lstm_create draws the reference's initial weights from rand() (it restates LstmLayer's constructor); the
+   * product's gmx_lstm_create touches no generator, and the reference's generation test samples from rand() afterwards
+   * (runner-utils.cpp:19, tester.cpp:296): the draws are made on a state of their own (glibc: rand() is random()) */
+  char scratch[256];
+  char* caller_state = initstate(1u, scratch, sizeof scratch);
   for (int s = 0; s < n_streams; ++s) l->st[s].l = gmxo_lstm_create();
+  setstate(caller_state);
   *out = l;
   return GMX_OK;
 }
@@ -185,7 +191,6 @@ int gmx_lstm_perceive(gmx_lstm* l, int stream, int byte) {
 int gmx_lstm_export(gmx_lstm* l, int stream, void* long_buf, size_t* long_bytes, void* short_buf, size_t* short_bytes) {
   if (!LSTM_ST(l, stream)) return GMX_ERR_INVALID;
   lstm_stream* st = &l->st[stream];
-  if ((long_buf || short_buf) && st->forward_pending) return GMX_ERR_STATE;
   *long_bytes = gmxo_lstm_export_long(st->l, 0);
   *short_bytes = gmxo_lstm_export_short(st->l, 0);
   if (long_buf) gmxo_lstm_export_long(st->l, (uint8_t*)long_buf);
@@ -198,7 +203,7 @@ int gmx_lstm_import(gmx_lstm* l, int stream, const void* long_buf, size_t long_b
   lstm_stream* st = &l->st[stream];
   if (gmxo_lstm_import_long(st->l, (const uint8_t*)long_buf, long_bytes)) return GMX_ERR_FORMAT;
   if (gmxo_lstm_import_short(st->l, (const uint8_t*)short_buf, short_bytes)) return GMX_ERR_FORMAT;
-  st->forward_pending = 0;
+  st->forward_pending = 1; /* (the file does not say: include/gmxmix.h) */
   st->last_byte = gmxo_lstm_last_input(st->l); /* the newest entry of input_history_ (include/gmxmix.h) */
   return GMX_OK;
 }

@@ -59,4 +59,8 @@ LSTM_CASES = {
     "lstm_alphabet16": (5000, 100, dict(seed=7, mask=15)),  # a learnable 16-symbol stream
     "lstm_long": (20000, 0, dict(seed=99)),                 # 200 backward passes, checksums only
     "lstm_update_limit": (305000, 0, dict(seed=3, mask=63)),  # Adam's step count reaches update_limit_ = 3000
+    # generation (runner-utils.cpp:199-209): from byte 230 on Predict and Perceive only -- 130 forwards on output
+    # layers no Perceive refreshes, across the epoch wrap at byte 300; the file at the end is the kind the
+    # reference's TestGeneration writes (tester.cpp:312): the newest forward never perceived
+    "lstm_generation": (360, 360, dict(seed=11, mask=63, nolearn_from=230)),
 }

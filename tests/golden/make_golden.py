@@ -97,6 +97,8 @@ def run_lstm_case(name):
     n_bytes, dump, kw = LSTM_CASES[name]
     args = [os.path.join(REF, "ref_lstm_harness"), "--bytes", str(n_bytes), "--dump", str(dump),
             "--seed", str(kw.get("seed", 0)), "--mask", str(kw.get("mask", 255))]
+    if "nolearn_from" in kw:
+        args += ["--nolearn-from", str(kw["nolearn_from"])]
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "d.bin")
         subprocess.run(args + ["--out", out], check=True, stdout=subprocess.DEVNULL)

@@ -58,6 +58,6 @@ def test_reference_tester_with_batched_compression(tmp_path):
     the stock build's."""
     _skip_unless("ref_tester_strict", "ref_tester_batched_shim", "ref_tester_chain_batched_shim")
     stock, batched, chain = run_all([("ref_tester_strict", 300), ("ref_tester_batched_shim", 300),
-                                     ("ref_tester_chain_batched_shim", 0)], 1200, tmp_path)
+                                     ("ref_tester_chain_batched_shim", 300)], 1200, tmp_path)
     compare(stock, batched)
-    compare(stock, chain, generation=False)   # (the chain's LSTM bank checkpoints at byte boundaries: no TestGeneration)
+    compare(stock, chain)

@@ -18,12 +18,12 @@ def test_reference_tester_with_adapters_equals_stock(tmp_path):
     gmx::GpuMixer; and the whole device chain -- LstmModel -> gmx::GpuLstmModel and the 41 Indirect ->
     gmx::GpuIndirect as well (the bank that runs when the LAST Indirect model is called, active_models back
     in index order, the .long sections written by the reference's own serialiser from what the adapters
-    staged).  The chain build runs without TestGeneration: it checkpoints after a Predict whose byte is
-    never perceived, which the device LSTM bank refuses (include/gmxmix.h)."""
+    staged).  TestGeneration included: it checkpoints after a Predict whose byte is never perceived, i.e. the
+    LSTM bank between its forward and its perceive (include/gmxmix.h)."""
     exes = ("ref_tester_strict", "ref_tester_shim", "ref_tester_chain_shim")
     for exe in exes:
         if not os.path.exists(os.path.join(REF, exe)):
             pytest.skip(f"oracle/_ref/{exe} not built (needs /root/reference: make -C oracle/ref_build dropin)")
-    stock, mixers, chain = run_all([(exes[0], 300), (exes[1], 300), (exes[2], 0)], 1500, tmp_path)
+    stock, mixers, chain = run_all([(exes[0], 300), (exes[1], 300), (exes[2], 300)], 1500, tmp_path)
     compare(stock, mixers)
-    compare(stock, chain, generation=False)
+    compare(stock, chain)

@@ -31,10 +31,10 @@ def test_batched_compress_100k_equals_stock_and_round_trips(gpu, tmp_path, exe):
 
 
 def test_reference_tester_chain_with_batched_compression_equals_stock(gpu, tmp_path):
-    """The same with the whole device chain (no TestGeneration: the LSTM bank checkpoints at byte boundaries)."""
+    """The same with the whole device chain."""
     need("ref_tester_strict", "ref_tester_chain_batched")
-    da, db = run_pair("ref_tester_strict", "ref_tester_chain_batched", 6000, 0, tmp_path)
-    compare(da, db, generation=False)
+    da, db = run_pair("ref_tester_strict", "ref_tester_chain_batched", 6000, 400, tmp_path)
+    compare(da, db)
 
 
 def test_reference_tester_with_batched_compression_equals_stock(gpu, tmp_path):

@@ -77,6 +77,41 @@ def test_lstm_generation_mode_and_restart(gpu, oracle):
     g.close()
 
 
+def test_lstm_generation_matches_reference_golden(gpu, oracle):
+    """Generation (runner-utils.cpp:199-209: Predict and Perceive, never Learn) against the REAL reference's
+    LstmModel (tests/golden/lstm_generation.npz): 230 bytes learned through the batched kernel, then 130 bytes
+    through gmx_lstm_forward alone -- Lstm::Predict on output layers no Perceive refreshes, across an epoch wrap --
+    the bits coded from the byte distribution on the host as the adapter does; every bit prediction, the
+    checksum, and the file the reference wrote at the end, in the state of its TestGeneration checkpoints
+    (tester.cpp:312): the newest forward never perceived."""
+    import goldenlib
+    meta, z = goldenlib.load("lstm_generation")
+    kw = meta["synth"]
+    N, N0 = meta["bytes"], kw["nolearn_from"]
+    ppm, data = oracle.lstm_synth(N, seed=kw["seed"], mask=kw["mask"])
+    m = oracle.LstmModel()                      # (only its bit-from-probs helper and initial weights are used)
+    g = gpu.LstmGroup(1)
+    g.set_weights(m.weights())
+    P, A, Cx = run_gpu(gpu, g, [(ppm[:N0], data[:N0])], chunk=N0)
+    assert np.array_equal(u32(P[0]), z["pred"][:N0]) and np.array_equal(A[0], z["active"][:N0])
+    m._pr.value = float(P[0, -1, -1])           # the blackboard slot as the last learned bit left it
+    last = int(data[N0 - 1])
+    tmb = None
+    for n in range(N0, N):
+        probs, ctx = g.forward(ppm[n], last)
+        pr, act, tmb = m.bits_from_probs(probs, data[n])
+        assert np.array_equal(u32(pr), z["pred"][n]) and np.array_equal(act, z["active"][n]) and ctx == z["ctx"][n], n
+        last = int(data[n])
+    lng, sh = g.export(0)                       # between that forward and a Perceive that never comes
+    sh = bytearray(sh)
+    for i, v in enumerate(tmb):                 # the range is the host's (include/gmxmix.h)
+        sh[4 * i:4 * i + 4] = int(v).to_bytes(4, "little")
+    assert (meta["top"], meta["mid"], meta["bot"]) == tmb
+    assert len(sh) == meta["short_size"] and oracle.fnv64_bytes(bytes(sh)) == meta["short_hash"]
+    assert oracle.fnv64_bytes(lng) == meta["long_hash"]
+    g.close()
+
+
 @pytest.mark.parametrize("name", ["lstm_short", "lstm_alphabet16", "lstm_long", "lstm_update_limit"])
 def test_lstm_kernel_matches_reference_goldens(gpu, oracle, name):
     """The fixtures made from the REAL reference LstmModel (tests/golden/lstm_*.npz), replayed
@@ -155,15 +190,36 @@ def test_lstm_checkpoint_import_export_copy(gpu, oracle):
     m2 = oracle.LstmModel(srand_seed=3)
     m2.import_state(*g.export(1))
     assert m2.export_short() == m.export_short()
-    # protocol and format errors
+    # Inside a byte -- LstmModel::WriteToDisk works at any bit (lstm-model.cpp:62-68) and the reference's
+    # TestGeneration checkpoints after a Predict whose byte is never perceived (tester.cpp:284, :312): the file of a
+    # bank between forward and perceive is the reference's there, goes into another bank, and both go on alike
     g.forward(ppm[0], int(data[-1]), stream=1)
-    with pytest.raises(gpu.GmxError):
-        g.export(1)                                # between Predict and Perceive: no byte boundary
-    g.perceive(int(data[0]), stream=1)
+    m.predict_byte(ppm[0], int(data[-1]))
+    mid = g.export(1)
+    assert mid == (m.export_long(), m.export_short())
+    g.import_(*mid, stream=0)
+    g2.copy_from(g, src_stream=1)                  # ... and a copy taken there
+    m.perceive_byte(int(data[0]))
+    for grp, st in ((g, 1), (g, 0), (g2, 0)):
+        grp.perceive(int(data[0]), stream=st)
+        assert grp.export(st) == (m.export_long(), m.export_short()), st
+    # generation: bytes predicted, never perceived, a checkpoint after each of them
+    for n in (1, 2, 3):
+        for grp, st in ((g, 1), (g, 0)):
+            grp.forward(ppm[n], int(data[n - 1]), stream=st)
+        m.predict_byte(ppm[n], int(data[n - 1]))
+        assert g.export(1) == g.export(0) == (m.export_long(), m.export_short()), n
+    # format errors
     with pytest.raises(gpu.GmxError):
         g.import_(lng[:-4], sh, stream=0)
     bad = bytearray(sh)
-    bad[0:4] = (200).to_bytes(4, "little")         # top_ of a checkpoint taken inside a byte
+    bad[0:4] = (300).to_bytes(4, "little")         # top_ out of range
+    with pytest.raises(gpu.GmxError):
+        g.import_(lng, bytes(bad), stream=0)
+    bad = bytearray(sh)
+    bad[8:12] = (201).to_bytes(4, "little")        # bot_ above mid_
+    bad[4:8] = (200).to_bytes(4, "little")
+    bad[0:4] = (255).to_bytes(4, "little")
     with pytest.raises(gpu.GmxError):
         g.import_(lng, bytes(bad), stream=0)
     g.close()
@@ -198,11 +254,20 @@ def test_lstm_per_byte_surface_for_decoding(gpu, oracle, sessions):
         probs, ctx = g.forward(ppm[n], last, stream=1)
         p_ref, c_ref = m.predict_byte(ppm[n], last)
         assert np.array_equal(u32(probs), u32(p_ref)) and ctx == c_ref, n
+        if n == 120:
+            # a checkpoint between this byte's Predict and its Perceive (the session hands the bank back with the
+            # forward done), restored into the other stream: both perceive the byte and stay the oracle's
+            mid = g.export(1)
+            assert mid == (m.export_long(), m.export_short())
+            g.import_(*mid, stream=0)
+            g.perceive(int(data[n]), stream=0)
         if n % 50 == 7:                            # a byte whose bits are predicted but never learned
             last = int(data[n])                    # (generation): the hidden state still moves on
             continue
         g.perceive(int(data[n]), stream=1)
         m.perceive_byte(int(data[n]))
+        if n == 120:
+            assert g.export(0) == g.export(1) == (m.export_long(), m.export_short())
         last = int(data[n])
     w, o = g.get_weights(1)
     assert np.array_equal(u32(w), u32(m.weights())) and np.array_equal(u32(o), u32(m.output_layer()))

@@ -16,7 +16,8 @@ def test_lstm_oracle_matches_reference(oracle, name):
     m = oracle.LstmModel()                       # srand(0xDEADBEEF) + the constructor chain
     assert m.weights_hash() == meta["init_weights_hash"]
     kw = meta["synth"]
-    h, pred, act, ctx = m.run_synth(meta["bytes"], seed=kw.get("seed", 0), mask=kw.get("mask", 255), dump=meta["dump"])
+    h, pred, act, ctx = m.run_synth(meta["bytes"], seed=kw.get("seed", 0), mask=kw.get("mask", 255), dump=meta["dump"],
+                                    nolearn_from=kw.get("nolearn_from"))
     if meta["dump"]:
         assert np.array_equal(pred.view(np.uint32), z["pred"])
         assert np.array_equal(act, z["active"]) and np.array_equal(ctx, z["ctx"])
