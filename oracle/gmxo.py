@@ -417,6 +417,8 @@ class LstmModel:
         L.gmxo_lstm_bit_from_probs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         probs = np.ascontiguousarray(probs, np.float32)
         top, mid, bot = C.c_int(255), C.c_int(127), C.c_int(0)
+        if not hasattr(self, "_lb"):
+            self._lb, self._pr, self._cx = C.c_uint32(0), C.c_float(0), C.c_uint32(0)
         pr = C.c_float(self._pr.value)
         out, act = np.zeros(8, np.float32), np.zeros(8, np.uint8)
         for k in range(8):

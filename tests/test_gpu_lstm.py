@@ -94,7 +94,8 @@ def test_lstm_generation_matches_reference_golden(gpu, oracle):
     g.set_weights(m.weights())
     P, A, Cx = run_gpu(gpu, g, [(ppm[:N0], data[:N0])], chunk=N0)
     assert np.array_equal(u32(P[0]), z["pred"][:N0]) and np.array_equal(A[0], z["active"][:N0])
-    m._pr.value = float(P[0, -1, -1])           # the blackboard slot as the last learned bit left it
+    import ctypes
+    m._lb, m._pr, m._cx = ctypes.c_uint32(0), ctypes.c_float(float(P[0, -1, -1])), ctypes.c_uint32(0)  # the slot as the last learned bit left it
     last = int(data[N0 - 1])
     tmb = None
     for n in range(N0, N):
