@@ -132,6 +132,13 @@ class MixerGroup:
                                    C.byref(ms) if timed else None), "gmx_group_run")
         return ms.value if timed else None
 
+    def run_ragged(self, batch, n_bits, learn=True):
+        """Stream s runs bits [0, n_bits[s]) of its records (gmx_group_run_ragged)."""
+        n = np.ascontiguousarray(n_bits, np.uint64)
+        assert n.shape == (self.S,)
+        check(self.L.gmx_group_run_ragged(self.h, batch.h, n.ctypes.data_as(C.POINTER(C.c_uint64)), 1 if learn else 0),
+              "gmx_group_run_ragged")
+
     # ---- persistence ----
     def export(self, stream=0):
         """(long_bytes, short_bytes) in the reference's checkpoint format."""

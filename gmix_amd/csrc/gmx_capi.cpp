@@ -174,6 +174,64 @@ static int xfer_wait(GmxXfer& x) {
 }
 
 
+// Per-stream counts of a launch over streams of different lengths (GmxRunArgs::T_list and its cousins): two
+// staging slots used alternately, a slot reused only when the launch that read it is done.
+struct GmxCountList {
+  uint64_t* dev[2] = {nullptr, nullptr};
+  uint64_t* host[2] = {nullptr, nullptr};  // pinned
+  hipEvent_t done[2] = {nullptr, nullptr};
+  bool busy[2] = {false, false};
+  size_t cap = 0;
+  unsigned seq = 0;
+};
+static void count_list_free(GmxCountList& c) {
+  for (int k = 0; k < 2; ++k) {
+    if (c.dev[k]) (void)hipFree(c.dev[k]);
+    if (c.host[k]) (void)hipHostFree(c.host[k]);
+    if (c.done[k]) (void)hipEventDestroy(c.done[k]);
+  }
+  c = GmxCountList();
+}
+// counts [n] -> device, queued on `st` in front of the kernel that reads them; *dev_out is that kernel's argument
+static int count_list_stage(GmxCountList& c, const uint64_t* counts, int n, hipStream_t st, const uint64_t** dev_out) {
+  const int k = (int)(c.seq++ & 1u);
+  if (c.busy[k]) {
+    HIPCHK(hipEventSynchronize(c.done[k]));
+    c.busy[k] = false;
+  }
+  if ((size_t)n > c.cap) {
+    for (int j = 0; j < 2; ++j) {
+      if (c.busy[j]) {
+        HIPCHK(hipEventSynchronize(c.done[j]));
+        c.busy[j] = false;
+      }
+      if (c.dev[j]) (void)hipFree(c.dev[j]);
+      if (c.host[j]) (void)hipHostFree(c.host[j]);
+      c.dev[j] = nullptr;
+      c.host[j] = nullptr;
+    }
+    c.cap = 0;
+    const size_t cap = (size_t)n + 64;
+    for (int j = 0; j < 2; ++j) {
+      HIPCHK(hipMalloc((void**)&c.dev[j], cap * sizeof(uint64_t)));
+      HIPCHK(hipHostMalloc((void**)&c.host[j], cap * sizeof(uint64_t), hipHostMallocDefault));
+      if (!c.done[j]) HIPCHK(hipEventCreateWithFlags(&c.done[j], hipEventDisableTiming));
+    }
+    c.cap = cap;
+  }
+  memcpy(c.host[k], counts, (size_t)n * sizeof(uint64_t));
+  HIPCHK(hipMemcpyAsync(c.dev[k], c.host[k], (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  *dev_out = c.dev[k];
+  return GMX_OK;
+}
+// ... and behind that kernel
+static int count_list_used(GmxCountList& c, hipStream_t st) {
+  const int k = (int)((c.seq - 1u) & 1u);
+  HIPCHK(hipEventRecord(c.done[k], st));
+  c.busy[k] = true;
+  return GMX_OK;
+}
+
 struct gmx_group {
   int device = 0;
   int S = 0;
@@ -206,6 +264,7 @@ struct gmx_group {
     float* patch_host = nullptr;   // pinned [kDecayAmbCap]
     size_t st_cap = 0;
   } decay[2];
+  GmxCountList counts;                // per-stream bit counts of ragged launches
   hipStream_t copy_stream = nullptr;  // uploads of the decay tables, beside the running kernel
   // record batches travel on streams of their own, beside the running kernel (BASELINE configs[3]:
   // "pinned hipMemcpyAsync double-buffered host->device probability batches"); events order them
@@ -545,6 +604,7 @@ extern "C" void gmx_group_destroy(gmx_group* g) {
     if (d.done) (void)hipEventDestroy(d.done);
     if (d.ready) (void)hipEventDestroy(d.ready);
   }
+  count_list_free(g->counts);
   if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
   if (g->up_stream) {
     (void)hipStreamSynchronize(g->up_stream);
@@ -749,8 +809,30 @@ static int prepare_decay(gmx_group* g, int s0, int ns, uint64_t T, int learn, gm
   return GMX_OK;
 }
 
+// Which kernel a launch takes.
+enum GmxKernelKind { GMX_K_SINGLE, GMX_K_WIDE, GMX_K_STOCK, GMX_K_BANK };
+static GmxKernelKind kernel_for(const gmx_group* g, unsigned mode) {
+  // Banks that are a single layer-0 mixer take the register-resident throughput kernel
+  // (gmx_single.hip); everything else, and every per-bit call, the general kernel.
+  const bool single = g->topo.m == 1 && g->topo.n <= 256 && (mode & GMX_MODE_PREDICT) &&
+                      !(mode & GMX_MODE_LATCH) && !g->force_general;
+  // The reference's own shape (90 inputs, 24/8/1, one skip input) runs with its rows in
+  // registers (gmx_stock.hip); it only needs the small part of the LDS image.
+  const bool stock = g->topo.n == 90 && g->topo.l0 == 24 && g->topo.l1 == 8 && g->topo.n_skip == 1 &&
+                     g->topo.has_final && g->topo.mx[23].stride == 128 && !g->force_general;
+  // The 256-input 24/8/1 bank (BASELINE configs[2]) likewise, two lanes per layer-0 row
+  // (gmx_wide.hip); batched Predict(+Learn) only.
+  const bool wide = g->topo.l0 == 24 && g->topo.l1 == 8 && g->topo.n_skip == 1 && g->topo.has_final &&
+                    ((g->topo.n == 256 && g->topo.mx[23].stride == 288) ||
+                     (g->topo.n == 90 && g->topo.mx[23].stride == 128 && g->stock_pairs && !g->stock_exact)) &&
+                    (mode & GMX_MODE_PREDICT) && !(mode & GMX_MODE_LATCH) && !g->force_general;
+  return single ? GMX_K_SINGLE : wide ? GMX_K_WIDE : stock ? GMX_K_STOCK : GMX_K_BANK;
+}
+
 static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint64_t T,
-                      unsigned mode, float* kernel_ms) {
+                      unsigned mode, float* kernel_ms, const uint64_t* n_list = nullptr) {
+  // n_list (host, [ns]): bits of each stream of the range, at most T; only for the kernels that take a count per
+  // block (gmx_stock_kernel, gmx_bank_kernel)
   if (T == 0) return GMX_OK;
   for (gmx_lockstep* ls : g->locksteps) ls->predicted = false;  // the latch no longer belongs to their Predict
   gmx_group::DecaySlot* dec = nullptr;
@@ -770,6 +852,10 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
   a.latch_out = g->latch_out;
   a.rec_stride = b->max_bits;
   a.T = T;
+  if (n_list) {
+    int rcl = count_list_stage(g->counts, n_list, ns, g->stream, &a.T_list);
+    if (rcl) return rcl;
+  }
   a.mode = mode | (g->stock_exact ? GMX_MODE_EXACT : 0u);
   a.stream_base = s0;
   a.rec_base = rec0;
@@ -779,20 +865,8 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
     if (rcx) return rcx;
   }
   if (kernel_ms) HIPCHK(hipEventRecord(g->ev0, g->stream));
-  // Banks that are a single layer-0 mixer take the register-resident throughput kernel
-  // (gmx_single.hip); everything else, and every per-bit call, the general kernel.
-  const bool single = g->topo.m == 1 && g->topo.n <= 256 && (mode & GMX_MODE_PREDICT) &&
-                      !(mode & GMX_MODE_LATCH) && !g->force_general;
-  // The reference's own shape (90 inputs, 24/8/1, one skip input) runs with its rows in
-  // registers (gmx_stock.hip); it only needs the small part of the LDS image.
-  const bool stock = g->topo.n == 90 && g->topo.l0 == 24 && g->topo.l1 == 8 && g->topo.n_skip == 1 &&
-                     g->topo.has_final && g->topo.mx[23].stride == 128 && !g->force_general;
-  // The 256-input 24/8/1 bank (BASELINE configs[2]) likewise, two lanes per layer-0 row
-  // (gmx_wide.hip); batched Predict(+Learn) only.
-  const bool wide = ((g->topo.n == 256 && g->topo.mx[23].stride == 288) ||
-                     (g->topo.n == 90 && g->topo.mx[23].stride == 128 && g->stock_pairs && !g->stock_exact)) &&
-                    g->topo.l0 == 24 && g->topo.l1 == 8 && g->topo.n_skip == 1 && g->topo.has_final &&
-                    (mode & GMX_MODE_PREDICT) && !(mode & GMX_MODE_LATCH) && !g->force_general;
+  const GmxKernelKind kind = kernel_for(g, mode);
+  const bool single = kind == GMX_K_SINGLE, wide = kind == GMX_K_WIDE, stock = kind == GMX_K_STOCK;
   if (single)
     HIPCHK(gmx_launch_single_kernel(g->topo_dev, &a, g->topo.n, g->single_variant, g->stream));
   else if (wide)
@@ -806,6 +880,10 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
                                   g->topo.mx[g->topo.l0 - 1].stride, g->stream));
   HIPCHK(hipEventRecord(dec->done, g->stream));
   dec->busy = true;
+  if (n_list) {
+    int rcl = count_list_used(g->counts, g->stream);
+    if (rcl) return rcl;
+  }
   {
     int rcn = batch_note_device_use(b);
     if (rcn) return rcn;
@@ -816,7 +894,7 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
     HIPCHK(hipEventElapsedTime(kernel_ms, g->ev0, g->ev1));
   }
   if (mode & GMX_MODE_LEARN)
-    for (int i = 0; i < ns; ++i) g->steps[s0 + i] += T;
+    for (int i = 0; i < ns; ++i) g->steps[s0 + i] += n_list ? n_list[i] : T;
   return GMX_OK;
 }
 
@@ -1049,16 +1127,28 @@ extern "C" int gmx_group_run(gmx_group* g, gmx_batch* b, uint64_t n_bits, int le
 // maximal runs of neighbouring streams with the same count share a launch, a stream with 0 bits sits out.
 extern "C" int gmx_group_run_ragged(gmx_group* g, gmx_batch* b, const uint64_t* n_bits, int learn) {
   if (!g || !b || b->g != g || b->S != g->S || !n_bits) return GMX_ERR_INVALID;
-  for (int s = 0; s < g->S; ++s)
+  uint64_t maxn = 0;
+  bool same = true;
+  for (int s = 0; s < g->S; ++s) {
     if (n_bits[s] > b->max_bits) return GMX_ERR_INVALID;
+    maxn = std::max(maxn, n_bits[s]);
+    same = same && n_bits[s] == n_bits[0];
+  }
   HIPCHK(hipSetDevice(g->device));
   int rc = sessions_close(g, false);
   if (rc) return rc;
   std::fill(g->fwd_done.begin(), g->fwd_done.end(), 0);
+  const unsigned mode = GMX_MODE_PREDICT | (learn ? GMX_MODE_LEARN : 0u);
+  if (same) return launch_run(g, b, 0, 0, g->S, maxn, mode, nullptr);
+  // The kernels with one stream per block take a count per block: ONE launch whatever the lengths (finished
+  // files leave holes among the streams; a launch per run of equal neighbours would put the runs one behind the
+  // other, each at a whole kernel's latency).  The one-mixer and lane-pair kernels run the runs.
+  const GmxKernelKind kind = kernel_for(g, mode);
+  if (kind == GMX_K_STOCK || kind == GMX_K_BANK) return launch_run(g, b, 0, 0, g->S, maxn, mode, nullptr, n_bits);
   for (int s0 = 0; s0 < g->S;) {
     int s1 = s0 + 1;
     while (s1 < g->S && n_bits[s1] == n_bits[s0]) ++s1;
-    rc = launch_run(g, b, s0, s0, s1 - s0, n_bits[s0], GMX_MODE_PREDICT | (learn ? GMX_MODE_LEARN : 0u), nullptr);
+    rc = launch_run(g, b, s0, s0, s1 - s0, n_bits[s0], mode, nullptr);
     if (rc) return rc;
     s0 = s1;
   }

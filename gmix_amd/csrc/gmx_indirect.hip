@@ -86,7 +86,7 @@ gmx_indirect_kernel(const GmxIndDev* __restrict__ dv, const GmxIndRunArgs a) {
   const int K = dv->k;
   const int s = a.stream_base + (int)blockIdx.x;
   const int rec = a.rec_base + (int)blockIdx.x;
-  const uint64_t T = a.T;
+  const uint64_t T = a.T_list ? a.T_list[blockIdx.x] : a.T;  // (wave-uniform: one stream per block)
   if (T == 0) return;
   uint8_t* const bank = a.banks + (uint64_t)s * dv->bank_bytes;
 

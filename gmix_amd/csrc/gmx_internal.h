@@ -62,7 +62,9 @@ struct GmxRunArgs {
   float* out_all;             // [S][*][m] or null
   float* latch_out;           // [S][m] outputs kept between forward and learn of the per-bit API
   uint64_t rec_stride;        // records per stream in the arrays above (max_bits of the batch)
-  uint64_t T;
+  uint64_t T;                 // bits per stream (the decay tables' pitch) ...
+  const uint64_t* T_list;     // ... or, not null: [n_streams] a count per block (<= T; 0: the stream sits the launch
+                              // out) -- streams of different lengths in ONE launch (files end at different bits)
   uint32_t mode;
   int32_t stream_base;        // bank of block 0
   int32_t rec_base;           // record-array stream index of block 0
@@ -212,6 +214,7 @@ struct GmxIndRunArgs {
   float* pred_out;         // [S][*][2k] or null
   uint8_t* act_out;        // [S][*][2k] or null
   uint64_t rec_stride, T;
+  const uint64_t* T_list;  // not null: [blocks] a bit count per block (<= T; 0: the stream sits the launch out)
   uint32_t learn;
   int32_t stream_base, rec_base;
   // optional: also write into the record arrays of a mixer batch (same streams, same bits)
@@ -283,6 +286,7 @@ struct GmxLstmRunArgs {
   uint8_t* act_out;        // [S][*][8]
   uint32_t* ctx_out;       // [S][*]
   uint64_t rec_stride, n_bytes;
+  const uint64_t* n_list;  // not null: [blocks] a byte count per block (<= n_bytes; 0: the stream sits the launch out)
   uint32_t learn, max_bptt;
   uint32_t phases;         // 1: Lstm::Predict, 2: the 8 bit predictions, 4: Lstm::Perceive (when learn)
   int32_t stream_base;     // bank of block 0 (records of block 0 are always stream 0 of the arrays)

@@ -140,7 +140,7 @@ gmx_bank_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
   const bool has_final = TFIN >= 0 ? (TFIN != 0) : (tp->has_final != 0);
   const int M = L0 + L1 + (has_final ? 1 : 0);
   const int MW = tp->mask_words;
-  const uint64_t T = a.T;
+  const uint64_t T = a.T_list ? a.T_list[blockIdx.x] : a.T;  // (wave-uniform: one stream per block)
   if (T == 0) return;
   uint8_t* const bank = a.banks + (uint64_t)s * tp->bank_bytes;
   const bool do_predict = (a.mode & GMX_MODE_PREDICT) != 0;
@@ -168,7 +168,7 @@ gmx_bank_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
   const uint32_t* const mask_s = HAS_MASK ? a.mask + (uint64_t)rec * RS * MW : nullptr;
   const uint32_t* const ctx_s = a.ctx + (uint64_t)rec * RS * M;
   const uint8_t* const bits_s = a.bits + (uint64_t)rec * RS;
-  const float* const dec_s = a.decay + (uint64_t)a.decay_idx[blockIdx.x] * T;
+  const float* const dec_s = a.decay + (uint64_t)a.decay_idx[blockIdx.x] * a.T;
   float* const p_s = a.p_out + (uint64_t)rec * RS;
   float* const oa_s = a.out_all ? a.out_all + (uint64_t)rec * RS * M : nullptr;
   float* const latch_s = a.latch_out + (uint64_t)s * M;

@@ -122,6 +122,9 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
   const GmxLstmDev& dv = *dvp;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int s = blockIdx.x;  // record stream; its bank:
+  // bytes of this stream in the launch (streams of different lengths share one: files end at different bytes)
+  const uint64_t NB = (!SESSION && a.n_list) ? a.n_list[s] : a.n_bytes;
+  if (!SESSION && NB == 0) return;
   float* const B = a.banks + (uint64_t)(a.stream_base + s) * dv.bank_floats;
   uint32_t* const scal = (uint32_t*)(B + dv.scal);
   uint32_t* const hist = (uint32_t*)(B + dv.input_history);
@@ -170,7 +173,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
   }
   if (tid < NC) cst = (B + dv.state)[tid];
   auto ppm_request = [&](uint64_t nn) {
-    const float* p = ppm_s + (nn < a.n_bytes ? nn : a.n_bytes - 1) * NI + tid;
+    const float* p = ppm_s + (nn < NB ? nn : NB - 1) * NI + tid;
     // into an AGPR: the value is in flight from here to ppm_landed(), and an accumulation register is nothing
     // the compiler would copy or park in scratch in between (this kernel spills a few VGPRs)
     asm volatile("global_load_dword %0, %1, off" : "=a"(ppm_n) : "v"(p) : "memory");
@@ -193,7 +196,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
     seen = word;
     if (tid == 0) __hip_atomic_store(&a.mb->done_seq, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   };
-  for (uint64_t n = 0; SESSION || n < a.n_bytes; ++n) {
+  for (uint64_t n = 0; SESSION || n < NB; ++n) {
     uint32_t byte = 0;
     if (SESSION) {
       if (fwd_after) {  // second half of GMX_MB_LEARN0_FWD

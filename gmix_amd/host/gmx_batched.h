@@ -111,12 +111,20 @@ class BatchedCompressor : public RunAheadSink {
   // 0, or a gmx_status (nothing is coded on the CPU instead: a Predictor whose mixers are not gmx::GpuMixer is
   // refused).  *output_bytes as runner_utils::Compress leaves it.
   int Run(unsigned long long input_bytes, std::ifstream* is, std::ofstream* os, unsigned long long* output_bytes) {
+    int rc = Begin(input_bytes);
+    return rc ? rc : Code(input_bytes, is, os, output_bytes);
+  }
+  // The two halves of Run.  Several compressors that share a pool all Begin before any of them Codes: a stream
+  // that joined the pool's ring late would hand in its chunks out of step with the others for the whole run, and
+  // every round would fall apart into launches of a few streams each.
+  int Begin(unsigned long long input_bytes) {
     if (!bank_) {
       fprintf(stderr, "gmx::BatchedCompress: this Predictor's mixers are not gmx::GpuMixer\n");
       return GMX_ERR_INVALID;
     }
     ShortTermMemory& stm = bank_->stm();
     const int sample_frequency = (int)(8 * input_bytes / 1000);  // runner-utils.cpp:47 (the call narrows to int)
+    sample_frequency_ = sample_frequency;
     if (opt_.analysis) {
       p_->EnableAnalysis(sample_frequency);
       F_ = sample_frequency > 0 ? sample_frequency : 0;
@@ -150,8 +158,11 @@ class BatchedCompressor : public RunAheadSink {
       }
     }
     uint64_t chunk = opt_.chunk_bits < 8 ? 8 : opt_.chunk_bits & ~7ull;
-    int rc = bank_->BeginRunAhead(this, chunk);
-    if (rc) return rc;
+    return bank_->BeginRunAhead(this, chunk);
+  }
+  int Code(unsigned long long input_bytes, std::ifstream* is, std::ofstream* os, unsigned long long* output_bytes) {
+    ShortTermMemory& stm = bank_->stm();
+    int rc = GMX_OK;
     const unsigned long long percent = 1 + (input_bytes / 10000);
     if (opt_.progress) {
       fprintf(stderr, "\r                     \r");
@@ -182,7 +193,7 @@ class BatchedCompressor : public RunAheadSink {
     if (rc == GMX_OK) rc = bank_->status();
     if (F_ > 0) {
       for (const Source& src : on_device_) stm.entropy[analysed_[src.column]] = src.ema;
-      p_->SetAnalysisFrequency(sample_frequency);
+      p_->SetAnalysisFrequency(sample_frequency_);
     }
     if (rc) return rc;
     enc_.Flush();
@@ -278,7 +289,7 @@ class BatchedCompressor : public RunAheadSink {
   Encoder enc_;
   BatchedOptions opt_;
   std::shared_ptr<GpuMixerBank> bank_;
-  int F_ = 0;
+  int F_ = 0, sample_frequency_ = 0;
   enum Kind { kMixer, kIndirect, kLstm };
   struct Source {   // an analysed entry whose values come from the device
     int column = 0;   // position in analysed_
@@ -360,6 +371,12 @@ inline int BatchedCompressFiles(std::vector<BatchedJob>& jobs, const BatchedOpti
         std::lock_guard<std::mutex> lk(construct);
         p.reset(new Predictor());
       }
+      std::unique_ptr<BatchedCompressor> c;
+      if (p) {
+        c.reset(new BatchedCompressor(p.get(), &data_out, opt));
+        job.status = c->Begin(job.input_bytes);  // every stream is in the pool's ring before the first chunk is recorded
+        if (job.status) c.reset();
+      }
       {  // all Predictors stand before the first one runs: the timed region is compression only
         std::unique_lock<std::mutex> lk(start_mu);
         if (++ready == S) {
@@ -369,11 +386,10 @@ inline int BatchedCompressFiles(std::vector<BatchedJob>& jobs, const BatchedOpti
           start_cv.wait(lk, [&] { return ready == S; });
         }
       }
-      if (!p) return;
       const clock::time_point a = clock::now();
-      {
-        BatchedCompressor c(p.get(), &data_out, opt);
-        job.status = c.Run(job.input_bytes, &data_in, &data_out, &job.output_bytes);
+      if (c) {
+        job.status = c->Code(job.input_bytes, &data_in, &data_out, &job.output_bytes);
+        c.reset();
       }
       ends[s] = clock::now();
       job.seconds = std::chrono::duration<double>(ends[s] - a).count();

@@ -127,6 +127,8 @@ class MixerPool {
   }
   ~MixerPool() {
     Uninstall();
+    if (trace_)  // GMX_POOL_TRACE=1: where the submitting thread's time went, call by call
+      for (auto& kv : step_seconds_) fprintf(stderr, "[gmx pool] %8.3f s  %s\n", kv.second, kv.first.c_str());
     for (int k = 0; k < 2; ++k) {
       if (ring_[k]) gmx_batch_destroy(ring_[k]);
       if (iring_[k]) gmx_ind_batch_destroy(iring_[k]);
@@ -389,8 +391,12 @@ class MixerPool {
     }
     int rc = GMX_OK;
     const char* what = "";
-#define GMX_POOL_STEP(call)              \
-  if (rc == GMX_OK && (rc = (call))) what = #call
+#define GMX_POOL_STEP(call)                                                                              \
+  if (rc == GMX_OK) {                                                                                    \
+    const auto step_t0 = std::chrono::steady_clock::now();                                               \
+    if ((rc = (call))) what = #call;                                                                     \
+    if (trace_) step_seconds_[#call] += std::chrono::duration<double>(std::chrono::steady_clock::now() - step_t0).count(); \
+  }
     if (maxn > 0) {
       if (parts_ & kLstm) {
         // LstmModel::Predict x 8 / Learn for every byte of the chunk, then its prediction into the mixers' records
@@ -499,6 +505,8 @@ class MixerPool {
   bool models_back_ = false;
   uint64_t T_ = 0, round_ = 0, bits_submitted_ = 0;
   double submit_seconds_ = 0, wait_seconds_ = 0;
+  const bool trace_ = getenv("GMX_POOL_TRACE") != nullptr;
+  std::map<std::string, double> step_seconds_;
   int n_pad_ = 0, mask_words_ = 0, M_ = 0, K_ = 0;
   int participants_ = 0, arrived_ = 0;
   std::vector<uint64_t> n_cur_, n_in_[2], n_bytes_;

@@ -94,6 +94,12 @@ class IndirectGroup:
                                       C.byref(ms) if timed else None), "gmx_indirect_run")
         return ms.value if timed else None
 
+    def run_ragged(self, batch, n_bits, learn=True, into=None):
+        n = np.ascontiguousarray(n_bits, np.uint64)
+        assert n.shape == (self.S,)
+        check(self.L.gmx_indirect_run_ragged(self.h, batch.h, n.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                             1 if learn else 0, into.h if into else None), "gmx_indirect_run_ragged")
+
     def export(self, stream=0):
         n = C.c_size_t(0)
         check(self.L.gmx_indirect_export(self.h, stream, None, C.byref(n)), "gmx_indirect_export")

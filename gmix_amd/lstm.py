@@ -106,6 +106,13 @@ class LstmGroup:
         return ms.value if timed else None
 
 
+    def run_ragged(self, batch, n_bytes, learn=True):
+        n = np.ascontiguousarray(n_bytes, np.uint64)
+        assert n.shape == (self.S,)
+        check(self.L.gmx_lstm_run_ragged(self.h, batch.h, n.ctypes.data_as(C.POINTER(C.c_uint64)), 1 if learn else 0),
+              "gmx_lstm_run_ragged")
+
+
 class LstmBatch:
     def __init__(self, group, max_bytes):
         self.g = group

@@ -6,7 +6,7 @@ LIST=${1:-"8 16 32 64"}
 N=${2:-30000}
 OUT=${3:-gpurun_out/many_scaling.txt}
 W=$(mktemp -d)
-cat DESIGN.md SURVEY.md INTEGRATION.md README.md > $W/corpus
+cat DESIGN.md SURVEY.md INTEGRATION.md README.md DESIGN.md SURVEY.md INTEGRATION.md README.md DESIGN.md SURVEY.md INTEGRATION.md README.md > $W/corpus
 REF=$PWD/oracle/_ref
 {
 echo "host: $(grep -m1 'model name' /proc/cpuinfo | cut -d: -f2), $(nproc) cpus visible, cpu.max $(cat /sys/fs/cgroup/cpu.max 2>/dev/null), $N bytes per file"
