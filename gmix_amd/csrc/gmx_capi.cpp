@@ -1144,7 +1144,8 @@ extern "C" int gmx_group_run_ragged(gmx_group* g, gmx_batch* b, const uint64_t* 
   // files leave holes among the streams; a launch per run of equal neighbours would put the runs one behind the
   // other, each at a whole kernel's latency).  The one-mixer and lane-pair kernels run the runs.
   const GmxKernelKind kind = kernel_for(g, mode);
-  if (kind == GMX_K_STOCK || kind == GMX_K_BANK) return launch_run(g, b, 0, 0, g->S, maxn, mode, nullptr, n_bits);
+  static const bool split = getenv("GMX_RAGGED_SPLIT") != nullptr;  // debugging: a launch per run of equal neighbours
+  if (!split && (kind == GMX_K_STOCK || kind == GMX_K_BANK)) return launch_run(g, b, 0, 0, g->S, maxn, mode, nullptr, n_bits);
   for (int s0 = 0; s0 < g->S;) {
     int s1 = s0 + 1;
     while (s1 < g->S && n_bits[s1] == n_bits[s0]) ++s1;

@@ -344,7 +344,7 @@ inline int BatchedCompressFiles(std::vector<BatchedJob>& jobs, const BatchedOpti
   std::mutex construct;  // Predictor::Predictor draws the LSTM's weights from rand() after srand() (predictor.cpp:18)
   std::mutex start_mu;
   std::condition_variable start_cv;
-  int ready = 0;
+  int built = 0, ready = 0;
   std::atomic<int> pinned{0};
   using clock = std::chrono::steady_clock;
   const clock::time_point tb = clock::now();
@@ -354,7 +354,6 @@ inline int BatchedCompressFiles(std::vector<BatchedJob>& jobs, const BatchedOpti
   for (int s = 0; s < S; ++s) {
     threads.emplace_back([&, s] {
       BatchedJob& job = jobs[s];
-      if (opt.pin_threads && PinThreadToDeviceNode(pool.device())) ++pinned;
       std::ifstream data_in(job.input_path, std::ios::in | std::ios::binary);
       std::ofstream data_out;
       std::unique_ptr<Predictor> p;
@@ -371,6 +370,18 @@ inline int BatchedCompressFiles(std::vector<BatchedJob>& jobs, const BatchedOpti
         std::lock_guard<std::mutex> lk(construct);
         p.reset(new Predictor());
       }
+      // Nothing else runs until every Predictor stands: its constructor seeds and draws from the process-wide
+      // rand() (predictor.cpp:18, lstm-layer.h:41), and whatever a thread next to it calls -- the HIP runtime coming
+      // up, a pinned allocation -- may draw from the same generator: one file's LSTM then starts from other weights
+      // than the reference's (seen: one output of several differing from `gmix -c`, always the same one).
+      {
+        std::unique_lock<std::mutex> lk(start_mu);
+        if (++built == S)
+          start_cv.notify_all();
+        else
+          start_cv.wait(lk, [&] { return built == S; });
+      }
+      if (opt.pin_threads && PinThreadToDeviceNode(pool.device())) ++pinned;
       std::unique_ptr<BatchedCompressor> c;
       if (p) {
         c.reset(new BatchedCompressor(p.get(), &data_out, opt));
