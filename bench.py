@@ -16,6 +16,7 @@ way (barrier, K steps, max over ranks) with its own roofline and one-core refere
   stock_real   the same with the row-change pattern of a real gmix run (the four bit-level contexts move every bit)
   stock_fresh  the same with every gate context new every bit (worst case)
   stock_S1     ONE stream of the reference's shape: what a single compressor sees
+  single_S1    ONE stream of configs[1]'s shape (the 256-step dependent sum: latency, not bandwidth)
   indirect     (one GPU) the 41 Indirect models in front of the mixers, 256 streams -- scripts/bench_indirect.py
   lstm         (one GPU) the LSTM byte model, 1024 streams, bytes/s -- scripts/bench_lstm.py
   e2e_S1 / e2e_S1_mixers / e2e_S64   (one GPU) whole files through the run-ahead compressor: the reference's feature
@@ -63,8 +64,10 @@ WORKLOADS = {
                    "(2 layer-0, 2 layer-1) every bit, forward+update"),
     "stock_S1": ("stock", 2, 1, 8192, 32_768, 800_000,
                  "ONE stream of the stock 24/8/1 topology (90 inputs), gate contexts redrawn every 8th bit, forward+update"),
+    "single_S1": ("single", 0, 1, 8192, 65_536, 20_000_000,
+                  "configs[1] for ONE stream: synthetic 256-input 1-layer mixer, random logits, forward+update"),
 }
-ALSO = ("synth3", "stock_held", "stock_real", "stock_fresh", "stock_S1")
+ALSO = ("synth3", "stock_held", "stock_real", "stock_fresh", "stock_S1", "single_S1")
 
 
 def aux_bench(script):
@@ -164,8 +167,9 @@ def pmc_traffic(kernel, S, T, ctx_mode, build):
 class Comm:
     """The three collectives of the bench (RCCL when torch.distributed is up, identity otherwise)."""
 
-    def __init__(self, dist, n_gpus, rank):
+    def __init__(self, dist, n_gpus, rank, pinned=None):
         self.dist, self.n_gpus, self.rank = dist, n_gpus, rank
+        self.pinned = pinned  # how many cpus of the GPU's NUMA node this rank was kept on (None: not pinned)
 
     def barrier(self):
         if self.dist is not None:
@@ -180,6 +184,10 @@ class Comm:
     def sum(self, v):
         from gmix_amd import shard
         return shard.sum_over_ranks(v, self.dist, device="cuda") if self.dist is not None else int(v)
+
+    def gather(self, v):
+        from gmix_amd import shard
+        return shard.gather_floats(v, self.dist, device="cuda") if self.dist is not None else [float(v)]
 
 
 def run_workload(name, comm, local_rank, streams=None, bits=None, steps=None, warmup=2, ring_n=4,
@@ -227,8 +235,13 @@ def run_workload(name, comm, local_rank, streams=None, bits=None, steps=None, wa
     gpu_ms = g.timer_stop()
     g.sync()
     comm.barrier()
-    elapsed = comm.max(time.perf_counter() - t0)
+    mine = time.perf_counter() - t0
+    elapsed = comm.max(mine)
     S_all = comm.sum(S)  # a rank with less free HBM runs fewer streams
+    rank_rates = comm.gather(S * T * steps / mine)  # every rank's own bits/s (its clock ends at the common barrier)
+    # the same launches once more, each bracketed by its own HIP events (outside the timed region: bracketing
+    # synchronises): how much a step varies
+    each = sorted(g.run(ring[k % len(ring)], T, learn=True, timed=True) for k in range(min(steps, 8)))
     bank_bytes = g.bank_bytes
     build = g.L.gmx_build_info().decode()
     for b in ring:
@@ -260,6 +273,7 @@ def run_workload(name, comm, local_rank, streams=None, bits=None, steps=None, wa
                    "parallelism": f"streams sharded over {comm.n_gpus} GPU(s), no collective on the data path"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel, "kernel_ms_avg": avg_ms,
+                     "kernel_ms_min": each[0], "kernel_ms_median": each[len(each) // 2], "kernel_ms_max": each[-1],
                      "algorithmic_bytes_per_bit": bytes_per_bit, "bytes_per_launch": bytes_per_launch,
                      "build": build},
     }
@@ -267,6 +281,9 @@ def run_workload(name, comm, local_rank, streams=None, bits=None, steps=None, wa
         out["roofline"].update(pmc_traffic(kernel, S, T, ctx_mode, build))
     except Exception as e:
         sys.stderr.write(f"[bench] no PMC summary: {e}\n")
+    if comm.n_gpus > 1:
+        out["per_rank"] = {"bits_per_s": rank_rates, "min": min(rank_rates), "max": max(rank_rates),
+                           "numa_pinned_cpus": comm.pinned}
     if want_cpu and comm.n_gpus == 1:
         out["cpu_baseline"] = cpu_baseline(topo, cpu_sample_bits or sample0, ctx_mode, ctx_mod)
     return out
@@ -335,10 +352,12 @@ def main():
         from gmix_amd import shard
         total = shard.sum_over_ranks(1, dist)
         slowest = shard.max_over_ranks(float(rank), dist)
+        each = shard.gather_floats(100.0 + rank, dist)       # the per-rank figures' collective
+        lowest = shard.min_over_ranks(100.0 + rank, dist)
         dist.barrier()
         if rank == 0:
             print(json.dumps({"rehearsal": True, "n_gpus": world, "ranks_counted": total, "max_rank": slowest,
-                              "value": None}), flush=True)
+                              "per_rank": each, "min": lowest, "value": None}), flush=True)
         dist.destroy_process_group()
         return
     if world > 1 or os.environ.get("GMX_BENCH_FORCE_DIST"):
@@ -352,7 +371,19 @@ def main():
             sys.exit(3)
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    comm = Comm(dist, world, rank)
+    pinned = None
+    try:
+        # the rank's host side (decay tables, record staging) on the cores next to its GPU
+        import ctypes
+        import gmix_amd
+        from gmix_amd import _lib, shard
+        buf = ctypes.create_string_buffer(64)
+        if _lib.lib().gmx_device_pci_bus_id(local_rank, buf, 64) == 0:
+            cpus = shard.pin_to_gpu_numa_node(buf.value.decode())
+            pinned = len(cpus) if cpus else None
+    except Exception as e:
+        sys.stderr.write(f"[bench] rank {rank}: not pinned to its GPU's NUMA node ({e})\n")
+    comm = Comm(dist, world, rank, pinned)
 
     head = run_workload(args.config, comm, local_rank, streams=args.streams, bits=args.bits, steps=args.steps,
                         warmup=args.warmup, ring_n=args.ring, ctx_mode=args.ctx_mode, ctx_mod=args.ctx_mod,
@@ -389,6 +420,11 @@ def main():
                     also[name] = aux_bench(script).measure(**kw)
                     if args.no_cpu_baseline:
                         also[name].pop("cpu_baseline", None)
+                    rf = also[name].get("roofline")
+                    if rf and rf.get("traffic") is None:   # the committed PMC summary of the same launch shape
+                        c = also[name]["config"]
+                        rf.update(pmc_traffic(rf["kernel"], c["streams"], c.get("bits_per_stream_per_step",
+                                              c.get("bytes_per_stream_per_step")), 0, rf.get("build")))
                 except Exception as e:
                     also[name] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
@@ -397,6 +433,8 @@ def main():
                "warmup": head["warmup"], "ms_per_step": head["ms_per_step"], "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": head["config"], "roofline": head["roofline"]}
+        if "per_rank" in head:
+            out["per_rank"] = head["per_rank"]
         if "cpu_baseline" in head:
             out["cpu_baseline"] = head["cpu_baseline"]
         if also:

@@ -68,6 +68,7 @@ def measure(streams=256, bits=4096, steps=8, warmup=2, cpu_sample_bits=400_000, 
         mg.sync()
     el = time.perf_counter() - t0
     avg = sum(ms) / len(ms)
+    build = g.L.gmx_build_info().decode()
     # algorithmic bytes per stream-bit: per model one 2-byte state pair read and written; the
     # record (contexts, bit_context, bit) read; two predictions + two flags per model written
     bpb = K * 4 + K * 4 + 5 + K * 10
@@ -78,7 +79,8 @@ def measure(streams=256, bits=4096, steps=8, warmup=2, cpu_sample_bits=400_000, 
                       "streams": S, "bits_per_stream_per_step": T, "bank_bytes_per_stream": g.bank_bytes},
            "roofline": {"bound": "hbm", "achieved": bpb * S * T / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": bpb * S * T / (avg * 1e-3) / 1e9 / 8000.0, "traffic": None, "kernel": "gmx_indirect_kernel",
-                        "kernel_ms_avg": avg, "algorithmic_bytes_per_bit": bpb}}
+                        "kernel_ms_avg": avg, "kernel_ms_min": min(ms), "kernel_ms_median": sorted(ms)[len(ms) // 2],
+                        "kernel_ms_max": max(ms), "algorithmic_bytes_per_bit": bpb, "build": build}}
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_indirect_harness")
     if os.path.exists(exe):
         n = cpu_sample_bits

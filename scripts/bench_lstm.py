@@ -30,14 +30,14 @@ def main():
 def measure(streams=1024, nbytes=200, steps=4, warmup=1, cpu_sample_bytes=20000, learn=True):
     """One result object in bench.py's conventions (also what bench.py's `also.lstm` carries)."""
     import gmix_amd
-    from oracle import gmxo
+    from gmix_amd import synth
     S, N = streams, nbytes
     g = gmix_amd.LstmGroup(S)
-    w = gmxo.LstmModel().weights()
+    w = synth.lstm_initial_weights()
     for s in range(S):
         g.set_weights(w, stream=s)
     b = gmix_amd.LstmBatch(g, N)
-    ppm, data = gmxo.lstm_synth(N, seed=1, mask=63)
+    ppm, data = synth.lstm_records(N, seed=1, mask=63)
     rng = np.random.default_rng(0)
     for s in range(S):   # same distributions, different byte streams
         b.ppm[s] = ppm
@@ -53,6 +53,7 @@ def measure(streams=1024, nbytes=200, steps=4, warmup=1, cpu_sample_bytes=20000,
     g.sync()
     el = time.perf_counter() - t0
     avg = sum(ms) / len(ms)
+    build = g.L.gmx_build_info().decode()
     # algorithmic HBM bytes per stream-byte: gate weights read once per forward (3 x 50 x 308 x 4),
     # the output layer read twice (forward, SGD) and its next ring slot written (3 x 256 x 51 x 4),
     # the records and the stored layer input (2 x 307 x 4 + 1024); per backward epoch (one per byte
@@ -67,7 +68,8 @@ def measure(streams=1024, nbytes=200, steps=4, warmup=1, cpu_sample_bytes=20000,
                       "bank_bytes_per_stream": g.bank_bytes, "bits_per_s": S * N * 8 * steps / el},
            "roofline": {"bound": "hbm", "achieved": bpb * S * N / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": bpb * S * N / (avg * 1e-3) / 1e9 / 8000.0, "traffic": None, "kernel": "gmx_lstm_kernel",
-                        "kernel_ms_avg": avg, "algorithmic_bytes_per_byte": bpb}}
+                        "kernel_ms_avg": avg, "kernel_ms_min": min(ms), "kernel_ms_median": sorted(ms)[len(ms) // 2],
+                        "kernel_ms_max": max(ms), "algorithmic_bytes_per_byte": bpb, "build": build}}
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_lstm_harness")
     if os.path.exists(exe):
         n = cpu_sample_bytes

@@ -30,8 +30,7 @@ def main():
     args = ap.parse_args()
     import gmix_amd
     import goldenlib
-    from gmix_amd import topology
-    from oracle import gmxo
+    from gmix_amd import synth, topology
     _, z = goldenlib.load("ind_tiny_dense")
     models = topology.stock_indirect()
     K, S, NB = len(models), args.streams, args.bytes
@@ -55,8 +54,8 @@ def main():
     lb = gmix_amd.LstmBatch(lg, NB)
     ibs = [gmix_amd.IndirectBatch(ig, T) for _ in range(2)]
     mbs = [gmix_amd.Batch(mg, T, outputs=False, mask=True) for _ in range(2)]
-    w = gmxo.LstmModel().weights()
-    ppm, data = gmxo.lstm_synth(NB, seed=1, mask=63)
+    w = synth.lstm_initial_weights()
+    ppm, data = synth.lstm_records(NB, seed=1, mask=63)
     rng = np.random.default_rng(0)
     for s in range(S):
         lg.set_weights(w, stream=s)

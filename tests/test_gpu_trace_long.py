@@ -14,12 +14,16 @@ from trace_common import REF_TRACE, ROOT, make_trace
 
 pytestmark = pytest.mark.gpu
 
+# GMX_CORPUS=/path/to/enwik8 replays the named data's first bytes as well (BASELINE.json configs[0] / [2]); the fixed
+# cases below use files that are on both boxes whatever else is
 CASES = {
     # name: (file present on both boxes, bytes, analysis, chunk bits)
     "text_30k": (os.path.join(ROOT, "SURVEY.md"), 30000, 0, 16384),
     "text_12k_analysis": (os.path.join(ROOT, "SURVEY.md"), 12000, 1, 5000),
     "binary_20k": (REF_TRACE, 20000, 0, 65536),
 }
+if os.environ.get("GMX_CORPUS"):
+    CASES["corpus_100k"] = (os.environ["GMX_CORPUS"], 100000, 0, 65536)
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
