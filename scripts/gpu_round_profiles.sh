@@ -17,7 +17,14 @@ done
 export GMX_LIB=$PWD/gmix_amd/libgmxmix_prof.so
 for c in "1 4096 2" "256 256 2" "1024 256 2" "1024 256 4" "1024 256 0"; do timeout -k 10 120 python3 scripts/stock_phase_profile.py $c; done > gpurun_out/stock_phase_profile.txt 2>&1
 unset GMX_LIB
+bash scripts/gpu_profile.sh stock_S1 --config stock_S1 --steps 4
 bash scripts/gpu_profile_indirect.sh
+bash scripts/gpu_profile_lstm.sh
 timeout -k 10 300 python3 scripts/bench_indirect.py > gpurun_out/indirect_bench.json 2> gpurun_out/indirect_bench.err
 timeout -k 10 300 python3 scripts/bench_real_trace.py > gpurun_out/real_trace.json 2> gpurun_out/real_trace.err
+# end to end: one file through every build, and many files side by side
+bash scripts/e2e_batched.sh 100000 gpurun_out/e2e.txt > /dev/null 2>&1
+bash scripts/many_scaling.sh "1 16 64 128" 30000 gpurun_out/many_scaling.txt > /dev/null 2>&1
+timeout -k 10 300 python3 scripts/bench_lstm.py > gpurun_out/lstm_bench.json 2> gpurun_out/lstm_bench.err
+timeout -k 10 300 python3 scripts/bench_pipeline.py > gpurun_out/pipeline_bench.json 2> gpurun_out/pipeline_bench.err
 echo done

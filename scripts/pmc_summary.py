@@ -54,7 +54,7 @@ build = None
 try:
     for line in open(os.path.join(src, "stats.log")):
         if line.startswith("{"):
-            build = json.loads(line)["roofline"].get("build")
+            build = json.loads(line)["roofline"].get("build")   # bench.py, bench_indirect.py and bench_lstm.py all say
 except Exception:
     pass
 out = {
