@@ -129,7 +129,7 @@ class MixerPool {
     Uninstall();
     if (trace_)  // GMX_POOL_TRACE=1: where the submitting thread's time went, call by call
       for (auto& kv : step_seconds_) fprintf(stderr, "[gmx pool] %8.3f s  %s\n", kv.second, kv.first.c_str());
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < kRing; ++k) {
       if (ring_[k]) gmx_batch_destroy(ring_[k]);
       if (iring_[k]) gmx_ind_batch_destroy(iring_[k]);
       if (lring_[k]) gmx_lstm_batch_destroy(lring_[k]);
@@ -324,7 +324,7 @@ class MixerPool {
       mixer_ctx_col_ = mixer_ctx_col;
       ind_ctx_col_ = ind_ctx_col;
       models_back_ = models;
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < kRing; ++k) {
         int rc = gmx_batch_create(&ring_[k], group_, T_, GMX_BATCH_OUTPUTS | GMX_BATCH_MASK);
         if (rc) return Fail("gmx_batch_create", rc);
         if (!gmx_batch_predictions(ring_[k]) || !gmx_batch_active_mask(ring_[k]) || !gmx_batch_contexts(ring_[k]) ||
@@ -346,15 +346,14 @@ class MixerPool {
       M_ = gmx_group_n_mixers(group_);
       K_ = (parts_ & kIndirect) ? gmx_indirect_n_models(ind_) : 0;
       n_cur_.assign(S_, 0);
-      n_in_[0].assign(S_, 0);
-      n_in_[1].assign(S_, 0);
+      for (int k = 0; k < kRing; ++k) n_in_[k].assign(S_, 0);
       n_bytes_.assign(S_, 0);
     } else if (parts != parts_ || lstm_slot != lstm_slot_ || mixer_ctx_col != mixer_ctx_col_ || ind_ctx_col != ind_ctx_col_) {
       return GMX_ERR_INVALID;  // Predictors of different make in one pool
     }
     models_back_ = models_back_ || models;
     n_cur_[slot] = 0;
-    n_in_[0][slot] = n_in_[1][slot] = 0;
+    for (int k = 0; k < kRing; ++k) n_in_[k][slot] = 0;
     streams_[slot].ra = true;
     streams_[slot].t = 0;
     Records(slot);
@@ -424,7 +423,7 @@ class MixerPool {
     }
     n_in_[c] = n_cur_;
     std::fill(n_cur_.begin(), n_cur_.end(), 0);
-    const int other = c ^ 1;
+    const int other = (c + 1) % kRing;  // the oldest chunk in flight: its arrays are the ones to fill next
     const auto lead_t1 = std::chrono::steady_clock::now();
     if (rc == GMX_OK && busy_[other]) {
       busy_[other] = false;
@@ -497,10 +496,14 @@ class MixerPool {
   std::condition_variable cv_;
   std::atomic<int> status_{0};
   std::string error_;
-  gmx_batch* ring_[2] = {nullptr, nullptr};
-  gmx_ind_batch* iring_[2] = {nullptr, nullptr};
-  gmx_lstm_batch* lring_[2] = {nullptr, nullptr};
-  bool busy_[2] = {false, false};
+  // Three sets of batches in turn: the hosts fill one while the device works on the two before it.  With two, the
+  // hosts could only start on chunk k+2 when chunk k had come back whole, and the longest stage of the chain (the
+  // LSTM) stood still meanwhile: one compressor ran at 4.0 us per bit, with three at the LSTM stage's own 3.4.
+  static constexpr int kRing = 3;
+  gmx_batch* ring_[kRing] = {};
+  gmx_ind_batch* iring_[kRing] = {};
+  gmx_lstm_batch* lring_[kRing] = {};
+  bool busy_[kRing] = {};
   int cur_ = 0, parts_ = 0, lstm_slot_ = -1, mixer_ctx_col_ = -1, ind_ctx_col_ = -1;
   bool models_back_ = false;
   uint64_t T_ = 0, round_ = 0, bits_submitted_ = 0;
@@ -509,7 +512,7 @@ class MixerPool {
   std::map<std::string, double> step_seconds_;
   int n_pad_ = 0, mask_words_ = 0, M_ = 0, K_ = 0;
   int participants_ = 0, arrived_ = 0;
-  std::vector<uint64_t> n_cur_, n_in_[2], n_bytes_;
+  std::vector<uint64_t> n_cur_, n_in_[kRing], n_bytes_;
 };
 
 // All mixers of one Predictor: one stream of a gmx_group (the Predictor's own, or a MixerPool's).
@@ -580,8 +583,8 @@ class GpuMixerBank {
   // The same without leaving run-ahead mode (a checkpoint in the middle of a file).
   int SyncRunAhead() {
     if (!st().ra) return GMX_OK;
-    int rc = Flush();
-    if (rc == GMX_OK) rc = Flush();
+    int rc = GMX_OK;  // what is recorded goes out, and every chunk in flight comes home
+    for (int k = 0; k < MixerPool::kRing && rc == GMX_OK; ++k) rc = Flush();
     return rc;
   }
 
