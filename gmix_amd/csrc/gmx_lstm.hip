@@ -196,6 +196,51 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
     seen = word;
     if (tid == 0) __hip_atomic_store(&a.mb->done_seq, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   };
+  // The 8 bit predictions of a byte (lstm-model.cpp:34-48) by the first 8 lanes of one wave: lane k sums the two
+  // halves of bit k's range of L.probs in order, lane 0 then walks the bits (a silent bit keeps the previous
+  // prediction) and stores the records.  Nothing later in the byte needs them, so a launch over whole records lets
+  // the FOURTH wave do byte n's while the other three run the gate chains of byte n+1 (L.probs is not rewritten
+  // before that byte's softmax): 2.5 of a byte's 26 us leave the chain of dependent phases.
+  auto bit_predictions = [&](uint32_t byte_b, uint64_t n_b, uint32_t context_b) {
+    float logit = 0.0f, state = 0.0f;
+    if (lane < 8) {
+      const int k = lane;
+      const int size = 256 >> k, half = size >> 1;
+      const int bot = k == 0 ? 0 : (int)((byte_b >> (8 - k)) << (8 - k));
+      const int mid = bot + half - 1, top = bot + size - 1;
+      // std::accumulate from 0.0f over the upper half, then on over the lower half
+      float num = 0.0f, denom;
+      if (half >= 4) {
+#pragma unroll 1
+        for (int o = 0; o < half; o += 64) num = ordered_sum4<16>(num, L.probs + mid + 1 + o, half - o < 64 ? half - o : 64);
+        denom = num;
+#pragma unroll 1
+        for (int o = 0; o < half; o += 64) denom = ordered_sum4<16>(denom, L.probs + bot + o, half - o < 64 ? half - o : 64);
+      } else {
+        for (int i = mid + 1; i <= top; ++i) num += L.probs[i];
+        denom = num;
+        for (int i = bot; i <= mid; ++i) denom += L.probs[i];
+      }
+      // SetPrediction (short-term-memory.cpp:187-191); a silent bit (denom == 0) keeps the slot
+      const float p = num / denom;
+      logit = gmx_logit(p);
+      state = denom != 0.0f ? (p == 0.5f ? 1.0f : 2.0f) : 0.0f;  // 0 silent, 1 inactive, 2 active
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {  // in bit order: a silent bit leaves the previous prediction
+      const float st = __shfl(state, k), lg = __shfl(logit, k);
+      if (lane == 0) {
+        if (st != 0.0f) prediction = lg;
+        pred_s[n_b * 8 + k] = prediction;
+        act_s[n_b * 8 + k] = st == 2.0f ? 1 : 0;
+      }
+    }
+    if (lane == 0) ctx_s[n_b] = context_b;
+  };
+  const bool defer_bits = !SESSION && a.phases == 7u;  // whole records: wave 3 takes the bits a byte late
+  bool bits_owed = false;
+  uint32_t owed_byte = 0, owed_context = 0;
+  uint64_t owed_n = 0;
   for (uint64_t n = 0; SESSION || n < NB; ++n) {
     uint32_t byte = 0;
     if (SESSION) {
@@ -282,7 +327,10 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
           }
         }
         L.nrm[wave][lane] = f;
+      } else if (wave == 3 && bits_owed) {
+        bit_predictions(owed_byte, owed_n, owed_context);
       }
+      bits_owed = false;
       __syncthreads();
       STAMP(2);  // gate chains
       if (wave < 3 && lane == 0) {
@@ -388,40 +436,17 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
     }
     STAMP(5);  // softmax sum, divide, context, early SGD
     // ======================= the 8 bit predictions (lstm-model.cpp:34-48) ====================
-    if ((phases & 2u) && tid < 8) {
-      const int k = tid;
-      const int size = 256 >> k, half = size >> 1;
-      const int bot = k == 0 ? 0 : (int)((byte >> (8 - k)) << (8 - k));
-      const int mid = bot + half - 1, top = bot + size - 1;
-      // std::accumulate from 0.0f over the upper half, then on over the lower half
-      float num = 0.0f, denom;
-      if (half >= 4) {
-#pragma unroll 1
-        for (int o = 0; o < half; o += 64) num = ordered_sum4<16>(num, L.probs + mid + 1 + o, half - o < 64 ? half - o : 64);
-        denom = num;
-#pragma unroll 1
-        for (int o = 0; o < half; o += 64) denom = ordered_sum4<16>(denom, L.probs + bot + o, half - o < 64 ? half - o : 64);
-      } else {
-        for (int i = mid + 1; i <= top; ++i) num += L.probs[i];
-        denom = num;
-        for (int i = bot; i <= mid; ++i) denom += L.probs[i];
+    if (phases & 2u) {
+      if (defer_bits) {  // by wave 3, beside the next byte's gate chains (or behind the loop)
+        bits_owed = true;
+        owed_byte = byte;
+        owed_n = n;
+        owed_context = context;
+      } else if (wave == 0) {
+        bit_predictions(byte, n, context);
       }
-      // SetPrediction (short-term-memory.cpp:187-191); a silent bit (denom == 0) keeps the slot
-      const float p = num / denom;
-      L.nrm[0][k] = gmx_logit(p);
-      L.ired[1 + 0] = 0;
-      L.nrm[1][k] = denom != 0.0f ? (p == 0.5f ? 1.0f : 2.0f) : 0.0f;  // 0 silent, 1 inactive, 2 active
     }
     __syncthreads();
-    if ((phases & 2u) && tid == 0) {
-      for (int k = 0; k < 8; ++k) {  // in bit order: a silent bit leaves the previous prediction
-        const float st = L.nrm[1][k];
-        if (st != 0.0f) prediction = L.nrm[0][k];
-        pred_s[n * 8 + k] = prediction;
-        act_s[n * 8 + k] = st == 2.0f ? 1 : 0;
-      }
-      ctx_s[n] = context;
-    }
     if (phases & 6u) {  // the byte is known from here on
       last_byte = byte;
       coded = 1;
@@ -719,6 +744,7 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
     __syncthreads();
     command_done();
   }
+  if (bits_owed && wave == 3) bit_predictions(owed_byte, owed_n, owed_context);  // the last byte's
   // state back to the bank
   if (tid < CP) {
     (B + dv.hidden)[tid] = L.hid[tid];
@@ -731,9 +757,10 @@ gmx_lstm_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmRunArgs a) {
     scal[2] = update_steps;
     scal[3] = last_byte;
     scal[4] = context;
-    scal[5] = __float_as_uint(prediction);
+    if (!defer_bits) scal[5] = __float_as_uint(prediction);
     scal[6] = coded;
   }
+  if (defer_bits && tid == 192) scal[5] = __float_as_uint(prediction);  // (wave 3's lane 0 walked the bits)
   if (SESSION) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
