@@ -77,7 +77,7 @@ def lib():
     L.gmx_batch_max_bits.argtypes = [vp]
     L.gmx_batch_max_bits.restype = u64
     for name in ("gmx_batch_predictions", "gmx_batch_active_mask", "gmx_batch_contexts",
-                 "gmx_batch_bits", "gmx_batch_p", "gmx_batch_outputs"):
+                 "gmx_batch_bits", "gmx_batch_p", "gmx_batch_outputs", "gmx_batch_last_outputs"):
         f = getattr(L, name)
         f.argtypes = [vp]
         f.restype = vp
@@ -179,7 +179,7 @@ ABI_SYMBOLS = [
     "gmx_group_bank_bytes", "gmx_group_reset", "gmx_group_sync", "gmx_group_timer_start", "gmx_group_timer_stop", "gmx_bank_forward", "gmx_bank_learn",
     "gmx_batch_create", "gmx_batch_destroy", "gmx_batch_n_pad", "gmx_batch_mask_words",
     "gmx_batch_max_bits", "gmx_batch_predictions", "gmx_batch_active_mask", "gmx_batch_contexts",
-    "gmx_batch_bits", "gmx_batch_p", "gmx_batch_outputs", "gmx_batch_upload", "gmx_batch_download",
+    "gmx_batch_bits", "gmx_batch_p", "gmx_batch_outputs", "gmx_batch_last_outputs", "gmx_batch_upload", "gmx_batch_download",
     "gmx_batch_wait", "gmx_batch_fill_synthetic", "gmx_group_run", "gmx_group_run_ragged", "gmx_bank_export",
     "gmx_bank_import", "gmx_bank_copy", "gmx_bank_memory_usage",
     "gmx_lockstep_create", "gmx_lockstep_destroy", "gmx_lockstep_batch", "gmx_lockstep_is_persistent", "gmx_lockstep_predict", "gmx_lockstep_learn", "gmx_lockstep_learn_predict",

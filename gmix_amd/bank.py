@@ -169,11 +169,11 @@ class MixerGroup:
 class Batch:
     """Records for up to max_bits bits of every stream of a group (gmx_batch)."""
 
-    def __init__(self, group, max_bits, outputs=True, mask=True):
+    def __init__(self, group, max_bits, outputs=True, mask=True, last_outputs=False):
         self.g = group
         self.L = group.L
         self.max_bits = int(max_bits)
-        self.flags = (BATCH_OUTPUTS if outputs else 0) | (BATCH_MASK if mask else 0)
+        self.flags = (BATCH_OUTPUTS if outputs else 0) | (BATCH_MASK if mask else 0) | (8 if last_outputs else 0)
         h = C.c_void_p()
         check(self.L.gmx_batch_create(C.byref(h), group.h, self.max_bits, self.flags), "gmx_batch_create")
         self.h = h
@@ -218,6 +218,11 @@ class Batch:
     @property
     def p(self):
         return self._view(self.L.gmx_batch_p, np.float32, (self.g.S, self.max_bits))
+
+    @property
+    def last_outputs(self):
+        """[S][M]: every mixer's output of each stream's last bit of the run (GMX_BATCH_LAST_OUTPUTS)."""
+        return self._view(self.L.gmx_batch_last_outputs, np.float32, (self.g.S, self.g.topo.n_mixers))
 
     @property
     def outputs(self):

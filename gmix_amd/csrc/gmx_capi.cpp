@@ -105,6 +105,15 @@ static int xfer_note_device_use(GmxXfer& x, hipStream_t main) {
   x.dev_rec = true;
   return GMX_OK;
 }
+// A writer on ANOTHER bank's stream (the LSTM's scatter, the Indirect models' `into`) is about to write this batch's
+// device arrays: it waits for what last touched THEM -- the batch's upload, the last device-side use -- not for
+// everything queued on the batch's own stream.  (Waiting for the whole stream put the LSTM of chunk k+1 behind the
+// mixers of chunk k-1 through the scatter between them: 1 ms of every 6 idle in the chain's longest stage.)
+static int xfer_writer_waits(GmxXfer& x, hipStream_t writer) {
+  if (x.up_rec) HIPCHK(hipStreamWaitEvent(writer, x.ev_up, 0));
+  if (x.dev_rec) HIPCHK(hipStreamWaitEvent(writer, x.ev_dev, 0));
+  return GMX_OK;
+}
 // Hardware queues.  The runtime maps a process's streams onto FOUR hardware queues per priority level, round robin,
 // and work on one queue runs in order whatever streams it came from.  The chain LSTM -> Indirect models -> mixers keeps
 // three compute streams busy at once (the LSTM of chunk k+1 beside the mixers of chunk k) plus their transfer
@@ -298,6 +307,7 @@ struct gmx_batch {
   uint8_t* d_bits = nullptr;
   float* d_p = nullptr;
   float* d_out = nullptr;
+  float* d_last = nullptr;         // [S][m] with GMX_BATCH_LAST_OUTPUTS
   // synthetic generator state
   uint64_t* d_rng = nullptr;
   uint64_t* d_tcount = nullptr;
@@ -310,6 +320,7 @@ struct gmx_batch {
   uint8_t* h_bits = nullptr;
   float* h_p = nullptr;
   float* h_out = nullptr;
+  float* h_last = nullptr;
   GmxXfer x;  // ordering of this batch's transfers against the kernels that use its device arrays
 };
 
@@ -337,6 +348,8 @@ struct gmx_lockstep {
   bool learn_inflight = false;   // the newest command is a learn nobody has waited for
 };
 
+enum GmxKernelKind : int;
+static GmxKernelKind kernel_for(const gmx_group* g, unsigned mode);
 // per-bit sessions (gmx_session.inc); sessions_close also stops the persistent lock-step waves of the group
 static int sessions_close(gmx_group* g, bool keep_forward);
 static int locksteps_stop(gmx_group* g, gmx_lockstep* except, bool keep_forward);
@@ -810,7 +823,7 @@ static int prepare_decay(gmx_group* g, int s0, int ns, uint64_t T, int learn, gm
 }
 
 // Which kernel a launch takes.
-enum GmxKernelKind { GMX_K_SINGLE, GMX_K_WIDE, GMX_K_STOCK, GMX_K_BANK };
+enum GmxKernelKind : int { GMX_K_SINGLE, GMX_K_WIDE, GMX_K_STOCK, GMX_K_BANK };
 static GmxKernelKind kernel_for(const gmx_group* g, unsigned mode) {
   // Banks that are a single layer-0 mixer take the register-resident throughput kernel
   // (gmx_single.hip); everything else, and every per-bit call, the general kernel.
@@ -849,6 +862,7 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
   a.decay_idx = dec->idx_dev;
   a.p_out = b->d_p;
   a.out_all = (b->flags & GMX_BATCH_OUTPUTS) ? b->d_out : nullptr;
+  a.out_last = (b->flags & GMX_BATCH_LAST_OUTPUTS) ? b->d_last : nullptr;
   a.latch_out = g->latch_out;
   a.rec_stride = b->max_bits;
   a.T = T;
@@ -867,6 +881,7 @@ static int launch_run(gmx_group* g, gmx_batch* b, int s0, int rec0, int ns, uint
   if (kernel_ms) HIPCHK(hipEventRecord(g->ev0, g->stream));
   const GmxKernelKind kind = kernel_for(g, mode);
   const bool single = kind == GMX_K_SINGLE, wide = kind == GMX_K_WIDE, stock = kind == GMX_K_STOCK;
+  if (a.out_last && (single || wide)) return GMX_ERR_INVALID;  // (gmx_batch_create refuses the flag for these shapes)
   if (single)
     HIPCHK(gmx_launch_single_kernel(g->topo_dev, &a, g->topo.n, g->single_variant, g->stream));
   else if (wide)
@@ -909,11 +924,11 @@ static void batch_free(gmx_batch* b) {
     auto& v = b->g->batches;
     v.erase(std::remove(v.begin(), v.end(), b), v.end());
   }
-  void* dv[] = {b->d_pred, b->d_mask, b->d_ctx, b->d_bits, b->d_p, b->d_out,
+  void* dv[] = {b->d_pred, b->d_mask, b->d_ctx, b->d_bits, b->d_p, b->d_out, b->d_last,
                 b->d_rng, b->d_tcount, b->d_pstate, b->d_cstate};
   for (void* p : dv)
     if (p) (void)hipFree(p);
-  void* hv[] = {b->h_pred, b->h_mask, b->h_ctx, b->h_bits, b->h_p, b->h_out};
+  void* hv[] = {b->h_pred, b->h_mask, b->h_ctx, b->h_bits, b->h_p, b->h_out, b->h_last};
   for (void* p : hv)
     if (p) (void)hipHostFree(p);
   xfer_free(b->x);
@@ -948,6 +963,10 @@ static int batch_alloc(gmx_batch** out, gmx_group* g, int S, uint64_t max_bits, 
   BCHK(hipMalloc((void**)&b->d_bits, R));
   BCHK(hipMalloc((void**)&b->d_p, R * sizeof(float)));
   if (flags & GMX_BATCH_OUTPUTS) BCHK(hipMalloc((void**)&b->d_out, R * t.m * sizeof(float)));
+  if (flags & GMX_BATCH_LAST_OUTPUTS) {
+    BCHK(hipMalloc((void**)&b->d_last, (size_t)S * t.m * sizeof(float)));
+    BCHK(hipMemset(b->d_last, 0, (size_t)S * t.m * sizeof(float)));
+  }
 #undef BCHK
   {
     int rcx = xfer_init(b->x);
@@ -963,6 +982,10 @@ static int batch_alloc(gmx_batch** out, gmx_group* g, int S, uint64_t max_bits, 
 
 extern "C" int gmx_batch_create(gmx_batch** out, gmx_group* g, uint64_t max_bits, unsigned flags) {
   if (!g) return GMX_ERR_INVALID;
+  if (flags & GMX_BATCH_LAST_OUTPUTS) {  // the one-mixer and lane-pair kernels do not keep them
+    const GmxKernelKind kind = kernel_for(g, GMX_MODE_PREDICT | GMX_MODE_LEARN);
+    if (kind == GMX_K_SINGLE || kind == GMX_K_WIDE) return GMX_ERR_INVALID;
+  }
   return batch_alloc(out, g, g->S, max_bits, flags);
 }
 
@@ -1001,6 +1024,10 @@ extern "C" uint8_t* gmx_batch_bits(gmx_batch* b) {
 }
 extern "C" const float* gmx_batch_p(gmx_batch* b) {
   return (b && b->g) ? lazy_host(b, &b->h_p, (size_t)b->S * b->max_bits) : nullptr;
+}
+extern "C" const float* gmx_batch_last_outputs(gmx_batch* b) {
+  if (!b || !b->g || !(b->flags & GMX_BATCH_LAST_OUTPUTS)) return nullptr;
+  return lazy_host(b, &b->h_last, (size_t)b->S * b->g->topo.m);
 }
 extern "C" const float* gmx_batch_outputs(gmx_batch* b) {
   if (!b || !b->g || !(b->flags & GMX_BATCH_OUTPUTS)) return nullptr;
@@ -1055,6 +1082,7 @@ extern "C" int gmx_batch_download(gmx_batch* b, uint64_t n_bits) {
   HIPCHK(hipSetDevice(g->device));
   if (!gmx_batch_p(b)) return GMX_ERR_NOMEM;
   if ((b->flags & GMX_BATCH_OUTPUTS) && !gmx_batch_outputs(b)) return GMX_ERR_NOMEM;
+  if ((b->flags & GMX_BATCH_LAST_OUTPUTS) && !gmx_batch_last_outputs(b)) return GMX_ERR_NOMEM;
   const size_t bytes = (size_t)b->S * n_bits * (4 + ((b->flags & GMX_BATCH_OUTPUTS) ? (size_t)t.m * 4 : 0));
   hipStream_t st = nullptr;
   int rc = xfer_begin_download(b->x, g->stream, &g->down_stream, bytes, &st);
@@ -1062,6 +1090,8 @@ extern "C" int gmx_batch_download(gmx_batch* b, uint64_t n_bits) {
   HIPCHK(copy_rows(b->h_p, b->d_p, 4, 1, b, n_bits, hipMemcpyDeviceToHost, st));
   if (b->flags & GMX_BATCH_OUTPUTS)
     HIPCHK(copy_rows(b->h_out, b->d_out, 4, t.m, b, n_bits, hipMemcpyDeviceToHost, st));
+  if (b->flags & GMX_BATCH_LAST_OUTPUTS)
+    HIPCHK(hipMemcpyAsync(b->h_last, b->d_last, (size_t)b->S * t.m * sizeof(float), hipMemcpyDeviceToHost, st));
   return xfer_end_download(b->x, st);
 }
 

@@ -60,6 +60,9 @@ struct GmxRunArgs {
   const uint32_t* decay_idx;  // [S] which table a stream uses
   float* p_out;               // [S][*]
   float* out_all;             // [S][*][m] or null
+  float* out_last;            // [S][m] or null: the m outputs of each stream's LAST bit of the launch only (what the
+                              // blackboard holds afterwards), for callers that need no more: the throughput build of
+                              // the stock kernel stores nothing else beside the probabilities
   float* latch_out;           // [S][m] outputs kept between forward and learn of the per-bit API
   uint64_t rec_stride;        // records per stream in the arrays above (max_bits of the batch)
   uint64_t T;                 // bits per stream (the decay tables' pitch) ...

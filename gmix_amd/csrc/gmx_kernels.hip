@@ -217,6 +217,7 @@ gmx_bank_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
   uint64_t rs_ld = 0;
   bool need = false;
 
+  float acc_last = 0.f;
   for (uint64_t t = 0; t <= T; ++t) {
     // ================= prefetch bit t (runs one iteration ahead of its compute) ==========
     if (t < T) {
@@ -396,6 +397,7 @@ gmx_bank_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
       // Predictor::Predict returns after clamping (predictor.cpp:369-375), all of them feed
       // Mixer::Learn (mixer.cpp:113-122).
       const float pl = gmx_logistic_tab(acc, s_tab);
+      acc_last = acc;
       if (lane == M - 1) gmx_vst4(p_s + tc, gmx_clamp_prob(pl));
       if (oa_s && is_mx) gmx_vst4(oa_s + tc * (uint64_t)M + lane, acc);
       if (do_latch && is_mx) gmx_vst4(latch_s + lane, acc);
@@ -540,6 +542,7 @@ gmx_bank_kernel(const GmxTopoDev* __restrict__ tp, const GmxRunArgs a) {
       dec_c = dec_n;
     }
   }
+  if (a.out_last && is_mx) a.out_last[(uint64_t)rec * M + lane] = acc_last;  // the last bit's outputs
   gmx_vmcnt<0>();
   if (is_mx && do_learn) {
     scal[0] = steps;

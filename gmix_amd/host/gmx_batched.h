@@ -143,6 +143,8 @@ class BatchedCompressor : public RunAheadSink {
         if (i >= N) {
           src.kind = kMixer;
           src.index = i - N;
+          // (the final mixer's average follows from the probability itself, below; any other mixer's needs its output)
+          if (i != (int)stm.model_enable_analysis.size() - 1) wants_all_outputs_ = true;
         } else if (i == lstm_slot) {
           src.kind = kLstm;
           wants_models_ = true;
@@ -203,12 +205,20 @@ class BatchedCompressor : public RunAheadSink {
 
   // RunAheadSink: a chunk is back
   bool WantsModels() const override { return wants_models_; }
+  bool WantsAllOutputs() const override { return wants_all_outputs_; }
   void Drain(const RunAheadView& v) override {
     for (uint64_t i = 0; i < v.n; ++i) {
       enc_.Encode(v.bits[i], v.p[i]);
       if (F_ > 0) {
         for (Source& src : on_device_) {  // Predictor::UpdateEntropy (predictor.cpp:439-469) on what the device produced
           float x;
+          if (src.kind == kMixer && !v.outputs) {
+            // The final mixer, from the probability: Predictor::Predict clamped Logistic(final_mixer_output) to
+            // [1e-4, 1 - 1e-4] (predictor.cpp:369-375), UpdateEntropy clamps the same Logistic to [0.01, 0.99]
+            // (predictor.cpp:453-457) -- the tighter clamp of the wider one is the tighter clamp.
+            src.ema = AverageOfProb(src.ema, v.p[i], v.bits[i]);
+            continue;
+          }
           if (src.kind == kMixer) {
             x = v.outputs[i * v.n_mixers + src.index];
           } else if (src.kind == kIndirect) {
@@ -238,8 +248,8 @@ class BatchedCompressor : public RunAheadSink {
     std::vector<unsigned long long> memory;
     size_t history;
   };
-  static double Average(double e, float x, int bit) {
-    float prob = Sigmoid::Logistic(x);
+  static double Average(double e, float x, int bit) { return AverageOfProb(e, Sigmoid::Logistic(x), bit); }
+  static double AverageOfProb(double e, float prob, int bit) {
     float eps = 0.01;
     if (prob < eps)
       prob = eps;
@@ -299,7 +309,7 @@ class BatchedCompressor : public RunAheadSink {
   };
   std::vector<int> analysed_;       // entropy indices with analysis on, ascending (the tables' columns)
   std::vector<Source> on_device_;
-  bool wants_models_ = false;
+  bool wants_models_ = false, wants_all_outputs_ = false;
   std::deque<Row> rows_;
   uint64_t recorded_ = 0, drained_ = 0;
 };

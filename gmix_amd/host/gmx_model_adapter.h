@@ -95,7 +95,9 @@ struct RunAheadView {
   uint64_t n = 0;
   const float* p = nullptr;         // [n] what Predictor::Predict() would have returned
   const uint8_t* bits = nullptr;    // [n] the bit that was then perceived
-  const float* outputs = nullptr;   // [n][n_mixers] every mixer's output (logit domain)
+  const float* outputs = nullptr;   // [n][n_mixers] every mixer's output (logit domain) -- only when the sink asked for
+                                    // them (RunAheadSink::WantsAllOutputs); else null, and
+  const float* last_outputs = nullptr;  // [n_mixers] the outputs of the newest of the n bits (what the blackboard holds)
   int n_mixers = 0;
   // with the Indirect models / the LSTM on the device too, and only when asked for (RunAheadSink::WantsModels):
   const float* ind_pred = nullptr;     // [n][2 * n_ind] what the models' blackboard slots held ([2i] indirect, [2i+1] run map)
@@ -108,6 +110,7 @@ struct RunAheadSink {
   virtual ~RunAheadSink() {}
   virtual void Drain(const RunAheadView& v) = 0;
   virtual bool WantsModels() const { return false; }  // also bring the device-side feature models' predictions back
+  virtual bool WantsAllOutputs() const { return false; }  // every mixer's output of every bit (else: the newest bit's)
 };
 
 // The device banks of up to n_streams Predictors -- ONE gmx_group, and one gmx_indirect / gmx_lstm where the
@@ -314,7 +317,8 @@ class MixerPool {
   // parts: which banks of the stream's Predictor are on the device (all streams of a pool alike);
   // lstm_slot / mixer_ctx_col / ind_ctx_col: where the LSTM's prediction and lstm_prediction_context go
   // (gmx_lstm_feed); models: the sink wants the feature models' predictions back as well
-  int Join(int slot, uint64_t chunk_bits, int parts, int lstm_slot, int mixer_ctx_col, int ind_ctx_col, bool models) {
+  int Join(int slot, uint64_t chunk_bits, int parts, int lstm_slot, int mixer_ctx_col, int ind_ctx_col, bool models,
+           bool all_outputs) {
     std::unique_lock<std::mutex> lk(mu_);
     if (status_.load()) return status_.load();
     if (!ring_[0]) {
@@ -324,11 +328,20 @@ class MixerPool {
       mixer_ctx_col_ = mixer_ctx_col;
       ind_ctx_col_ = ind_ctx_col;
       models_back_ = models;
+      all_outputs_ = all_outputs;
       for (int k = 0; k < kRing; ++k) {
-        int rc = gmx_batch_create(&ring_[k], group_, T_, GMX_BATCH_OUTPUTS | GMX_BATCH_MASK);
+        // the probabilities, and of the mixers' outputs only the newest bit's (the blackboard) unless the sink
+        // analyses mixers other than the final one: the kernel's throughput build stores nothing else
+        int rc = all_outputs_ ? GMX_ERR_INVALID
+                              : gmx_batch_create(&ring_[k], group_, T_, GMX_BATCH_LAST_OUTPUTS | GMX_BATCH_MASK);
+        if (rc == GMX_ERR_INVALID) {  // (shapes whose kernels keep all outputs or none)
+          all_outputs_ = true;
+          rc = gmx_batch_create(&ring_[k], group_, T_, GMX_BATCH_OUTPUTS | GMX_BATCH_MASK);
+        }
         if (rc) return Fail("gmx_batch_create", rc);
         if (!gmx_batch_predictions(ring_[k]) || !gmx_batch_active_mask(ring_[k]) || !gmx_batch_contexts(ring_[k]) ||
-            !gmx_batch_bits(ring_[k]) || !gmx_batch_p(ring_[k]) || !gmx_batch_outputs(ring_[k]))
+            !gmx_batch_bits(ring_[k]) || !gmx_batch_p(ring_[k]) ||
+            !(all_outputs_ ? gmx_batch_outputs(ring_[k]) : gmx_batch_last_outputs(ring_[k])))
           return Fail("gmx_batch (pinned arrays)", GMX_ERR_NOMEM);
         if (parts_ & kIndirect) {
           if ((rc = gmx_ind_batch_create(&iring_[k], ind_, T_))) return Fail("gmx_ind_batch_create", rc);
@@ -348,8 +361,9 @@ class MixerPool {
       n_cur_.assign(S_, 0);
       for (int k = 0; k < kRing; ++k) n_in_[k].assign(S_, 0);
       n_bytes_.assign(S_, 0);
-    } else if (parts != parts_ || lstm_slot != lstm_slot_ || mixer_ctx_col != mixer_ctx_col_ || ind_ctx_col != ind_ctx_col_) {
-      return GMX_ERR_INVALID;  // Predictors of different make in one pool
+    } else if (parts != parts_ || lstm_slot != lstm_slot_ || mixer_ctx_col != mixer_ctx_col_ || ind_ctx_col != ind_ctx_col_ ||
+               (all_outputs && !all_outputs_)) {
+      return GMX_ERR_INVALID;  // Predictors of different make in one pool (or a sink that needs what the ring does not carry)
     }
     models_back_ = models_back_ || models;
     n_cur_[slot] = 0;
@@ -456,7 +470,12 @@ class MixerPool {
     gmx_batch* b = ring_[cur_];
     v->n = n_in_[cur_][slot];
     v->p = gmx_batch_p(b) + (size_t)slot * T_;
-    v->outputs = gmx_batch_outputs(b) + (size_t)slot * T_ * M_;
+    if (all_outputs_) {
+      v->outputs = gmx_batch_outputs(b) + (size_t)slot * T_ * M_;
+      v->last_outputs = v->n ? v->outputs + (size_t)(v->n - 1) * M_ : nullptr;
+    } else {
+      v->last_outputs = gmx_batch_last_outputs(b) + (size_t)slot * M_;
+    }
     v->n_mixers = M_;
     v->bits = gmx_batch_bits(b) + (size_t)slot * T_;
     if (models_back_ && (parts_ & kIndirect)) {
@@ -505,7 +524,7 @@ class MixerPool {
   gmx_lstm_batch* lring_[kRing] = {};
   bool busy_[kRing] = {};
   int cur_ = 0, parts_ = 0, lstm_slot_ = -1, mixer_ctx_col_ = -1, ind_ctx_col_ = -1;
-  bool models_back_ = false;
+  bool models_back_ = false, all_outputs_ = false;
   uint64_t T_ = 0, round_ = 0, bits_submitted_ = 0;
   double submit_seconds_ = 0, wait_seconds_ = 0;
   const bool trace_ = getenv("GMX_POOL_TRACE") != nullptr;
@@ -1460,7 +1479,8 @@ inline int GpuMixerBank::BeginRunAhead(RunAheadSink* sink, uint64_t chunk_bits) 
     }
     Unstage();
   }
-  int rc = pool_->Join(slot_, chunk_bits, parts, lstm_slot, mixer_ctx_col, ind_ctx_col, sink && sink->WantsModels());
+  int rc = pool_->Join(slot_, chunk_bits, parts, lstm_slot, mixer_ctx_col, ind_ctx_col, sink && sink->WantsModels(),
+                       sink && sink->WantsAllOutputs());
   if (rc) return rc;
   T_ = pool_->chunk_bits();
   n_pad_ = pool_->n_pad_;
@@ -1479,7 +1499,7 @@ inline int GpuMixerBank::Flush() {
     if (sink_) sink_->Drain(v);
     // mixer.cpp:99-105: where the Mixer::Predict calls of the newest bit left their results
     const int M = v.n_mixers;
-    const float* o = v.outputs + (size_t)(v.n - 1) * M;
+    const float* o = v.last_outputs;
     size_t j = 0;
     for (int k = 0; k < stm_.num_layer0_mixers; ++k) stm_.mixer_layer0_outputs[k] = o[j++];
     for (int k = 0; k < stm_.num_layer1_mixers; ++k) stm_.mixer_layer1_outputs[k] = o[j++];

@@ -117,6 +117,11 @@ int gmx_bank_learn(gmx_group* g, int stream, int bit);
 /* ---- batched surface: T bits for every stream in one launch ---------------------------- */
 #define GMX_BATCH_OUTPUTS 1u   /* also return all M mixer outputs per bit */
 #define GMX_BATCH_MASK 2u      /* records carry an active mask; otherwise every slot is active */
+#define GMX_BATCH_LAST_OUTPUTS 8u  /* return the M outputs of each stream's LAST bit of a run only -- what the
+                                    * blackboard (mixer_layer0_outputs, ..., final_mixer_output) holds afterwards; a
+                                    * compressor needs no more, and the throughput build of the kernel then stores
+                                    * nothing else beside the probabilities.  GMX_ERR_INVALID for the shapes that run
+                                    * through the one-mixer and lane-pair kernels (use GMX_BATCH_OUTPUTS there). */
 int gmx_batch_create(gmx_batch** out, gmx_group* g, uint64_t max_bits, unsigned flags);
 void gmx_batch_destroy(gmx_batch* b);
 /* Layout of the staging arrays (all stream-major, then bit):
@@ -125,7 +130,8 @@ void gmx_batch_destroy(gmx_batch* b);
  *   contexts    [S][max_bits][M]
  *   bits        [S][max_bits]
  *   p           [S][max_bits]          clamped probabilities (what Predict() returns)
- *   outputs     [S][max_bits][M]       with GMX_BATCH_OUTPUTS */
+ *   outputs     [S][max_bits][M]       with GMX_BATCH_OUTPUTS
+ *   last_outputs[S][M]                 with GMX_BATCH_LAST_OUTPUTS */
 int gmx_batch_n_pad(const gmx_batch* b);
 int gmx_batch_mask_words(const gmx_batch* b);
 uint64_t gmx_batch_max_bits(const gmx_batch* b);
@@ -135,6 +141,7 @@ uint32_t* gmx_batch_contexts(gmx_batch* b);
 uint8_t* gmx_batch_bits(gmx_batch* b);
 const float* gmx_batch_p(gmx_batch* b);
 const float* gmx_batch_outputs(gmx_batch* b);   /* NULL without GMX_BATCH_OUTPUTS */
+const float* gmx_batch_last_outputs(gmx_batch* b);  /* [S][M] after gmx_batch_download; NULL without GMX_BATCH_LAST_OUTPUTS */
 /* Transfers run on streams of their own, ordered by events against the kernels that use the
  * batch: an upload starts when the last run of THIS batch is done and overlaps whatever runs on
  * other batches (double buffering: run(A); upload(B); run(B); download(A); wait(A); refill A ...);

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Kernel timeline of the run-ahead chain for ONE file: where the stages of neighbouring chunks overlap and where they wait.
+cd /root/repo
+W=$(mktemp -d); head -c ${1:-20000} DESIGN.md > $W/f0
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $W/prof -o run -- oracle/_ref/gmix_chain_many -T ${2:-2048} $W/out $W/f0 > $W/j.json 2> $W/err
+f=$(find $W/prof -name "*kernel_trace.csv" | head -1)
+python3 - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+ev = []
+for r in rows:
+    n = r["Kernel_Name"]
+    k = "lstm" if "gmx_lstm_kernel" in n else "ind" if "gmx_indirect_kernel" in n else "mix" if "gmx_stock_kernel" in n else "feed" if "scatter" in n else None
+    if k: ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), k))
+ev.sort()
+t0 = ev[0][0]
+by = {}
+for s, e, k in ev: by.setdefault(k, []).append((s - t0, e - t0))
+for k, v in by.items():
+    d = [(e - s) / 1e6 for s, e in v]
+    gaps = [(v[i + 1][0] - v[i][1]) / 1e6 for i in range(len(v) - 1)]
+    mid = slice(len(v) // 4, 3 * len(v) // 4)
+    print(f"{k:5s} n={len(v):4d} dur ms avg {sum(d[mid]) / max(1, len(d[mid])):.3f}  gap-to-next ms avg {sum(gaps[mid]) / max(1, len(gaps[mid])):.3f}  period {(v[mid][-1][0] - v[mid][0][0]) / 1e6 / max(1, len(v[mid]) - 1):.3f}")
+print("first rounds (ms since first kernel): kind start end")
+for s, e, k in ev[len(ev) // 2: len(ev) // 2 + 16]: print(f"  {k:5s} {(s - t0) / 1e6:9.3f} {(e - t0) / 1e6:9.3f}")
+PY
+rm -rf $W

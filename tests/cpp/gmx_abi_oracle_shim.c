@@ -72,9 +72,13 @@ struct gmx_batch {
   float *pred, *p, *out;
   uint32_t *mask, *ctx;
   uint8_t* bits;
+  float* last;
+  unsigned flags;
 };
 int gmx_batch_create(gmx_batch** out, gmx_group* g, uint64_t max_bits, unsigned flags) {
-  if (!out || !g || !max_bits || flags != (GMX_BATCH_OUTPUTS | GMX_BATCH_MASK)) return GMX_ERR_INVALID;
+  if (!out || !g || !max_bits ||
+      (flags != (GMX_BATCH_OUTPUTS | GMX_BATCH_MASK) && flags != (GMX_BATCH_LAST_OUTPUTS | GMX_BATCH_MASK)))
+    return GMX_ERR_INVALID;
   gmx_batch* b = (gmx_batch*)calloc(1, sizeof(*b));
   const size_t R = (size_t)g->S * max_bits;
   b->g = g;
@@ -87,6 +91,8 @@ int gmx_batch_create(gmx_batch** out, gmx_group* g, uint64_t max_bits, unsigned 
   b->bits = (uint8_t*)calloc(R, 1);
   b->p = (float*)calloc(R, 4);
   b->out = (float*)calloc(R * g->m, 4);
+  b->last = (float*)calloc((size_t)g->S * g->m, 4);
+  b->flags = flags;
   *out = b;
   return GMX_OK;
 }
@@ -98,6 +104,7 @@ void gmx_batch_destroy(gmx_batch* b) {
   free(b->bits);
   free(b->p);
   free(b->out);
+  free(b->last);
   free(b);
 }
 int gmx_batch_n_pad(const gmx_batch* b) { return b->n_pad; }
@@ -109,7 +116,8 @@ uint32_t* gmx_batch_active_mask(gmx_batch* b) { return b->mask; }
 uint32_t* gmx_batch_contexts(gmx_batch* b) { return b->ctx; }
 uint8_t* gmx_batch_bits(gmx_batch* b) { return b->bits; }
 const float* gmx_batch_p(gmx_batch* b) { return b->p; }
-const float* gmx_batch_outputs(gmx_batch* b) { return b->out; }
+const float* gmx_batch_outputs(gmx_batch* b) { return (b->flags & GMX_BATCH_OUTPUTS) ? b->out : 0; }
+const float* gmx_batch_last_outputs(gmx_batch* b) { return (b->flags & GMX_BATCH_LAST_OUTPUTS) ? b->last : 0; }
 int gmx_batch_upload(gmx_batch* b, uint64_t n) { return (b && n <= b->T) ? GMX_OK : GMX_ERR_INVALID; }
 int gmx_batch_download(gmx_batch* b, uint64_t n) { return (b && n <= b->T) ? GMX_OK : GMX_ERR_INVALID; }
 int gmx_batch_wait(gmx_batch* b) { return b ? GMX_OK : GMX_ERR_INVALID; }
@@ -125,6 +133,7 @@ int gmx_group_run_ragged(gmx_group* g, gmx_batch* b, const uint64_t* n_bits, int
         if (b->mask[r * b->mw + (i >> 5)] >> (i & 31) & 1u) act[na++] = i;
       b->p[r] = gmxo_predict(g->bs[s], b->pred + r * b->n_pad, act, na, b->ctx + r * g->m, b->out + r * g->m);
       if (learn) gmxo_learn(g->bs[s], b->bits[r]);
+      if (t + 1 == n_bits[s]) memcpy(b->last + (size_t)s * g->m, b->out + r * g->m, (size_t)g->m * 4);
     }
   }
   return GMX_OK;

@@ -24,6 +24,12 @@ def test_mixer_group_ragged_runs_equal_the_oracle(gpu, oracle, shape):
     S, T = 7, 96
     g = gpu.MixerGroup(topo, S)
     b = gpu.Batch(g, T, outputs=True, mask=True)
+    # ... and a batch that brings back the outputs of each stream's LAST bit only (GMX_BATCH_LAST_OUTPUTS: what a
+    # compressor needs for the blackboard; the one-mixer kernel does not keep them)
+    bl = None if shape == "single" else gpu.Batch(g, T, outputs=False, mask=True, last_outputs=True)
+    if shape == "single":
+        with pytest.raises(gpu.GmxError):
+            gpu.Batch(g, T, outputs=False, mask=True, last_outputs=True)
     banks = [oracle.Bank(n, topo.skip, topo.mixers) for _ in range(S)]
     rng = np.random.default_rng(3)
     for rnd, counts in enumerate([[96, 96, 0, 17, 96, 64, 1], [0, 96, 0, 96, 5, 96, 96], [8, 8, 8, 0, 0, 0, 96]]):
@@ -43,7 +49,27 @@ def test_mixer_group_ragged_runs_equal_the_oracle(gpu, oracle, shape):
                 assert np.array_equal(u32(b.p[s, :k]), u32(want[s][0])), (rnd, s)
                 assert np.array_equal(u32(b.outputs[s, :k]), u32(want[s][1])), (rnd, s)
             assert g.export(s) == (banks[s].export_long(), banks[s].export_short()), (rnd, s)
+        if bl is not None:  # one more ragged round through the other kind of batch
+            counts2 = [5, 0, 96, 40, 96, 1, 96]
+            want = []
+            for s in range(S):
+                pred, act, ctx, bits = oracle.synth(n, m, T, seed=1000 + 100 * rnd + s, ctx_mode=3, ctx_mod=5, zero_mod=4, bit_mode=1)
+                bl.set_records(s, pred, act, ctx, bits)
+                k = counts2[s]
+                want.append(banks[s].run(pred[:k], act[:k], ctx[:k], bits[:k]) if k else None)
+            bl.upload(T)
+            g.run_ragged(bl, counts2)
+            bl.download(T)
+            bl.wait()
+            for s in range(S):
+                k = counts2[s]
+                if k:
+                    assert np.array_equal(u32(bl.p[s, :k]), u32(want[s][0])), (rnd, s)
+                    assert np.array_equal(u32(bl.last_outputs[s]), u32(want[s][1][k - 1])), (rnd, s)
+                assert g.export(s) == (banks[s].export_long(), banks[s].export_short()), (rnd, s)
     b.close()
+    if bl is not None:
+        bl.close()
     g.close()
 
 
