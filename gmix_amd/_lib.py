@@ -121,6 +121,8 @@ def lib():
     L.gmx_indirect_import.argtypes = [vp, i32, vp, C.c_size_t]
     L.gmx_indirect_copy.argtypes = [vp, i32, vp, i32]
     L.gmx_indirect_memory_usage.argtypes = [vp, i32, C.POINTER(u64)]
+    L.gmx_indirect_slots_get.argtypes = [vp, i32, C.POINTER(C.c_float)]
+    L.gmx_indirect_slots_set.argtypes = [vp, i32, C.POINTER(C.c_float)]
     L.gmx_lstm_create.argtypes = [C.POINTER(vp), i32, i32]
     L.gmx_lstm_destroy.argtypes = [vp]
     L.gmx_lstm_destroy.restype = None
@@ -189,7 +191,7 @@ ABI_SYMBOLS = [
     "gmx_ind_batch_contexts", "gmx_ind_batch_bit_contexts", "gmx_ind_batch_bits",
     "gmx_ind_batch_predictions", "gmx_ind_batch_active", "gmx_ind_batch_upload", "gmx_ind_batch_download",
     "gmx_ind_batch_wait", "gmx_ind_batch_fill_synthetic", "gmx_indirect_run", "gmx_indirect_run_ragged", "gmx_indirect_export",
-    "gmx_indirect_import", "gmx_indirect_copy", "gmx_indirect_memory_usage",
+    "gmx_indirect_import", "gmx_indirect_copy", "gmx_indirect_memory_usage", "gmx_indirect_slots_get", "gmx_indirect_slots_set",
     "gmx_lstm_create", "gmx_lstm_destroy", "gmx_lstm_n_streams", "gmx_lstm_bank_bytes", "gmx_lstm_reset",
     "gmx_lstm_sync", "gmx_lstm_set_weights", "gmx_lstm_get_weights", "gmx_lstm_batch_create",
     "gmx_lstm_batch_destroy", "gmx_lstm_batch_ppm", "gmx_lstm_batch_bytes", "gmx_lstm_batch_predictions",

@@ -105,6 +105,8 @@ struct RunAheadView {
   int n_ind = 0;
   const float* lstm_pred = nullptr;    // [n / 8][8] the LSTM's slot, bit by bit
   const uint8_t* lstm_active = nullptr;
+  const uint32_t* lstm_context = nullptr;  // [n / 8] ShortTermMemory::lstm_prediction_context of every byte (whenever the
+                                           // LSTM is on the device: the blackboard keeps the newest)
 };
 struct RunAheadSink {
   virtual ~RunAheadSink() {}
@@ -422,7 +424,7 @@ class MixerPool {
       if (parts_ & kLstm) {
         GMX_POOL_STEP(gmx_lstm_feed(lstm_, lring_[c], maxn / 8, ring_[c], lstm_slot_, mixer_ctx_col_,
                                     (parts_ & kIndirect) && ind_ctx_col_ >= 0 ? iring_[c] : nullptr, ind_ctx_col_));
-        if (models_back_) GMX_POOL_STEP(gmx_lstm_batch_download(lring_[c], maxn / 8));
+        GMX_POOL_STEP(gmx_lstm_batch_download(lring_[c], maxn / 8));  // (44 bytes per byte: the context at least is wanted)
       }
       if (parts_ & kIndirect) {
         GMX_POOL_STEP(gmx_indirect_run_ragged(ind_, iring_[c], n_cur_.data(), 1, ring_[c]));
@@ -443,7 +445,7 @@ class MixerPool {
       busy_[other] = false;
       GMX_POOL_STEP(gmx_batch_wait(ring_[other]));
       if (models_back_ && (parts_ & kIndirect)) GMX_POOL_STEP(gmx_ind_batch_wait(iring_[other]));
-      if (models_back_ && (parts_ & kLstm)) GMX_POOL_STEP(gmx_lstm_batch_wait(lring_[other]));
+      if (parts_ & kLstm) GMX_POOL_STEP(gmx_lstm_batch_wait(lring_[other]));
     }
 #undef GMX_POOL_STEP
     if (rc) Fail(what, rc);
@@ -483,9 +485,10 @@ class MixerPool {
       v->ind_active = gmx_ind_batch_active(iring_[cur_]) + (size_t)slot * T_ * 2 * K_;
       v->n_ind = K_;
     }
-    if (models_back_ && (parts_ & kLstm)) {
+    if (parts_ & kLstm) {
       v->lstm_pred = gmx_lstm_batch_predictions(lring_[cur_]) + (size_t)slot * (T_ / 8) * 8;
       v->lstm_active = gmx_lstm_batch_active(lring_[cur_]) + (size_t)slot * (T_ / 8) * 8;
+      v->lstm_context = gmx_lstm_batch_contexts(lring_[cur_]) + (size_t)slot * (T_ / 8);
     }
     n_in_[cur_][slot] = 0;
     streams_[slot].t = 0;
@@ -585,6 +588,7 @@ class GpuMixerBank {
   // prediction slots of Indirect model i ([2i] indirect, [2i+1] run map), the LSTM's slot (-1: on the host)
   std::vector<int> IndirectSlots() const;
   int LstmSlot() const;
+  int SlotsHome();  // the device-side models' prediction slots, back onto the blackboard
 
   // From the next Predict on, the device-side models record instead of compute; results reach `sink` one chunk
   // later.  Every bit must be Predict -> Perceive -> Learn (the paths that know their bits:
@@ -604,6 +608,7 @@ class GpuMixerBank {
     if (!st().ra) return GMX_OK;
     int rc = GMX_OK;  // what is recorded goes out, and every chunk in flight comes home
     for (int k = 0; k < MixerPool::kRing && rc == GMX_OK; ++k) rc = Flush();
+    if (rc == GMX_OK) rc = SlotsHome();
     return rc;
   }
 
@@ -1050,6 +1055,23 @@ class GpuIndirectBank {
   }
   void PredictAll(ShortTermMemory& stm);
   void ToBlackboard(ShortTermMemory& stm);
+  // The models' blackboard slots between ShortTermMemory::predictions and the bank (gmx_indirect_slots_set / _get):
+  // while batches run the bank's copy is the current one, and the reference writes these with the blackboard.
+  void SlotsToDevice(const ShortTermMemory& stm) {
+    for (size_t i = 0; i < descs_.size(); ++i) {
+      pred_[2 * i] = stm.predictions[descs_[i].slot_indirect];
+      pred_[2 * i + 1] = stm.predictions[descs_[i].slot_run_map];
+    }
+    Call("gmx_indirect_slots_set", [&] { return gmx_indirect_slots_set(h_, slot_, pred_.data()); });
+  }
+  void SlotsFromDevice(ShortTermMemory& stm) {
+    Call("gmx_indirect_slots_get", [&] { return gmx_indirect_slots_get(h_, slot_, pred_.data()); });
+    if (pool_->status()) return;
+    for (size_t i = 0; i < descs_.size(); ++i) {
+      stm.predictions[descs_[i].slot_indirect] = pred_[2 * i];
+      stm.predictions[descs_[i].slot_run_map] = pred_[2 * i + 1];
+    }
+  }
   void Deliver(ShortTermMemory& stm, const float* pred, const uint8_t* active) {  // from gmx_chain_forward
     pending_ = false;
     std::copy(pred, pred + pred_.size(), pred_.begin());
@@ -1446,6 +1468,7 @@ inline int GpuMixerBank::BeginRunAhead(RunAheadSink* sink, uint64_t chunk_bits) 
   if (s.indirect) {
     s.indirect->Settle();
     s.indirect->pending_ = false;
+    s.indirect->SlotsToDevice(stm_);
     parts |= MixerPool::kIndirect;
   }
   if (s.lstm) {
@@ -1491,6 +1514,11 @@ inline int GpuMixerBank::BeginRunAhead(RunAheadSink* sink, uint64_t chunk_bits) 
   return GMX_OK;
 }
 
+inline int GpuMixerBank::SlotsHome() {
+  if (st().indirect) st().indirect->SlotsFromDevice(stm_);
+  return status();
+}
+
 inline int GpuMixerBank::Flush() {
   RunAheadView v;
   int rc = pool_->Arrive(slot_, st().t, &v);
@@ -1504,7 +1532,12 @@ inline int GpuMixerBank::Flush() {
     for (int k = 0; k < stm_.num_layer0_mixers; ++k) stm_.mixer_layer0_outputs[k] = o[j++];
     for (int k = 0; k < stm_.num_layer1_mixers; ++k) stm_.mixer_layer1_outputs[k] = o[j++];
     if (j < (size_t)M) stm_.final_mixer_output = o[j];
-    if (st().lstm) st().lstm->range_on_device_ = true;
+    if (st().lstm) {
+      st().lstm->range_on_device_ = true;
+      // lstm-model.cpp:25-33: what the newest byte's LstmModel::Predict left on the blackboard
+      if (v.lstm_context && v.n >= 8) stm_.lstm_prediction_context = v.lstm_context[v.n / 8 - 1];
+      if (v.lstm_pred) stm_.predictions[st().lstm->prediction_index()] = v.lstm_pred[v.n - 1];  // (a silent bit repeats the slot)
+    }
   }
   return GMX_OK;
 }

@@ -114,6 +114,17 @@ class IndirectGroup:
     def copy_from(self, src, src_stream=0, dst_stream=0):
         check(self.L.gmx_indirect_copy(self.h, dst_stream, src.h, src_stream), "gmx_indirect_copy")
 
+    def slot_values(self, stream=0):
+        """What the models' two blackboard slots hold ([2i] indirect, [2i+1] run map)."""
+        v = np.zeros(2 * self.K, np.float32)
+        check(self.L.gmx_indirect_slots_get(self.h, stream, v.ctypes.data_as(C.POINTER(C.c_float))), "gmx_indirect_slots_get")
+        return v
+
+    def set_slot_values(self, values, stream=0):
+        v = np.ascontiguousarray(values, np.float32)
+        assert v.shape == (2 * self.K,)
+        check(self.L.gmx_indirect_slots_set(self.h, stream, v.ctypes.data_as(C.POINTER(C.c_float))), "gmx_indirect_slots_set")
+
     def memory_usage(self, model):
         v = C.c_uint64(0)
         check(self.L.gmx_indirect_memory_usage(self.h, model, C.byref(v)), "gmx_indirect_memory_usage")

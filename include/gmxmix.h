@@ -311,6 +311,14 @@ int gmx_indirect_import(gmx_indirect* ib, int stream, const void* buf, size_t by
 int gmx_indirect_copy(gmx_indirect* dst, int dst_stream, gmx_indirect* src, int src_stream);
 int gmx_indirect_memory_usage(gmx_indirect* ib, int model, uint64_t* bytes);
 
+/* What the two blackboard slots of each model hold ([2i] indirect, [2i+1] run map): ShortTermMemory::predictions at
+ * slot_indirect / slot_run_map, which the reference writes with the blackboard (short-term-memory.cpp:4) and which a
+ * silent model leaves as they were (indirect.cpp:35-44).  The bank carries them through batches and chain calls, where
+ * the host's copy goes stale (no mixer reads a silent slot, so only what is WRITTEN OUT depends on them): a caller that
+ * takes a stream from the per-bit surface to the batched one sets them before and gets them after. */
+int gmx_indirect_slots_get(gmx_indirect* ib, int stream, float* values /* [2 * n_models] */);
+int gmx_indirect_slots_set(gmx_indirect* ib, int stream, const float* values /* [2 * n_models] */);
+
 /* ==== LSTM byte model ==========================================
  * The reference's LstmModel (models/lstm-model.h:12-31): Lstm(256, 256, 50, 1, 100, 0.03, 10) over
  * the PPM byte distribution, predicting the next byte once per byte and the 8 bits from that

@@ -118,6 +118,16 @@ int gmx_indirect_copy(gmx_indirect* dst, int ds, gmx_indirect* src, int ss) {
   memcpy(dst->bs[ds]->pred, src->bs[ss]->pred, 2 * dst->b->k * sizeof(float));
   return GMX_OK;
 }
+int gmx_indirect_slots_get(gmx_indirect* ib, int stream, float* values) {
+  if (!IND_BANK(ib, stream) || !values) return GMX_ERR_INVALID;
+  memcpy(values, ib->bs[stream]->pred, 2 * ib->b->k * sizeof(float));
+  return GMX_OK;
+}
+int gmx_indirect_slots_set(gmx_indirect* ib, int stream, const float* values) {
+  if (!IND_BANK(ib, stream) || !values) return GMX_ERR_INVALID;
+  memcpy(ib->bs[stream]->pred, values, 2 * ib->b->k * sizeof(float));
+  return GMX_OK;
+}
 int gmx_indirect_memory_usage(gmx_indirect* ib, int model, uint64_t* bytes) {
   if (!ib || model < 0 || model >= ib->b->k) return GMX_ERR_INVALID;
   *bytes = gmxo_ind_memory_usage(ib->b, model);

@@ -9,7 +9,7 @@ import os
 import pytest
 
 from batched_common import REF, compress_pair, corpus, gmix, need, run_many, same_outputs
-from dropin_common import compare, run_all
+from dropin_common import checkpoint_after_batches, compare, run_all, same_checkpoint
 
 
 def _skip_unless(*exes):
@@ -61,3 +61,16 @@ def test_reference_tester_with_batched_compression(tmp_path):
                                      ("ref_tester_chain_batched_shim", 300)], 1200, tmp_path)
     compare(stock, batched)
     compare(stock, chain)
+
+
+@pytest.mark.parametrize("exe,chunk", [("gmix_batched_ckpt_shim", 2048), ("gmix_chain_batched_ckpt_shim", 1000)])
+def test_state_left_behind_equals_the_per_bit_loop(tmp_path, exe, chunk):
+    """What a run-ahead compression LEAVES: Predictor::WriteCheckpoint straight after gmx::BatchedCompressor over
+    601 bytes equals the checkpoint the reference's tester writes after the same 601 bytes through its
+    Predict/Encode/Perceive/Learn loop (tester.cpp:32-59) -- the banks' state as the reference's serialisers write
+    it, the blackboard (mixer outputs, final output, lstm_prediction_context from the device in `chain`), the
+    LSTM's byte-range state, every host model."""
+    _skip_unless("ref_tester_strict", exe)
+    (stock,) = run_all([("ref_tester_strict", 0)], 1200, tmp_path)
+    ck = checkpoint_after_batches(exe, stock, 1200, chunk, tmp_path)
+    same_checkpoint(os.path.join(stock, "restart"), ck)

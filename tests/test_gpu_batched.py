@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 import pytest
 
 from batched_common import REF, compress_pair, corpus, gmix, need, run_many, same_outputs
-from dropin_common import compare, run_pair
+from dropin_common import checkpoint_after_batches, compare, run_all, run_pair, same_checkpoint
 
 pytestmark = pytest.mark.gpu
 
@@ -92,3 +92,15 @@ def test_small_chunks_and_ragged_ends(gpu, tmp_path, exe, chunk):
     for k, f in enumerate(files):
         gmix("gmix_strict", "-c", f, tmp_path / f"ref{k}", tmp_path)
         assert (tmp_path / f"ref{k}").read_bytes() == (tmp_path / "out" / f"{k}.gmix").read_bytes(), f"file {k}"
+
+
+def test_state_left_behind_equals_the_per_bit_loop(gpu, tmp_path):
+    """What a run-ahead compression LEAVES on the device and on the blackboard: Predictor::WriteCheckpoint straight
+    after gmx::BatchedCompressor over 20 001 bytes (79 chunks of 2 048 bits and a ragged one; chain: 161 of 1 000)
+    equals the checkpoint the stock tester writes after the same bytes through its per-bit loop
+    (tester.cpp:32-59): the three banks' state as the reference's serialisers write it, the mixers' outputs, the
+    Indirect models' and the LSTM's prediction slots (gmx_indirect_slots_get) and lstm_prediction_context."""
+    need("ref_tester_strict", "gmix_batched_ckpt", "gmix_chain_batched_ckpt")
+    (stock,) = run_all([("ref_tester_strict", 0)], 40000, tmp_path)
+    for exe, chunk in (("gmix_batched_ckpt", 2048), ("gmix_chain_batched_ckpt", 1000)):
+        same_checkpoint(os.path.join(stock, "restart"), checkpoint_after_batches(exe, stock, 40000, chunk, tmp_path))

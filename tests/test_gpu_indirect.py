@@ -307,6 +307,16 @@ def test_indirect_device_synth_is_the_oracles_stream(gpu, oracle):
         assert np.array_equal(u32(first[0][s]), u32(p[:500])) and np.array_equal(first[1][s], a[:500])
         assert np.array_equal(u32(b.predictions[s, :400]), u32(p[500:])) and np.array_equal(b.active[s, :400], a[500:])
         assert g.export(s) == ob.export()
+        # the blackboard slots as the bank holds them: the last bit's (a silent model repeats its slot)
+        assert np.array_equal(u32(g.slot_values(s)), u32(p[-1]))
+    # ... and as a caller sets them: silent models report what was set
+    v = np.arange(1, 7, dtype=np.float32)
+    g.set_slot_values(v, 1)
+    assert np.array_equal(g.slot_values(1), v) and not np.array_equal(g.slot_values(0), v)
+    g.reset()                                                # every state "never seen": all six slots stay silent
+    g.set_slot_values(v, 1)
+    pr, ac = g.forward(np.array([1, 2, 3], np.uint32), 1, stream=1)
+    assert np.array_equal(pr, v) and not ac.any()
     b.close()
     g.close()
 
