@@ -8,16 +8,16 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gmix_amd
-from oracle import gmxo
+from gmix_amd import synth
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 g = gmix_amd.LstmGroup(S)
-w = gmxo.LstmModel().weights()
+w = synth.lstm_initial_weights()
 for s in range(S):
     g.set_weights(w, stream=s)
 b = gmix_amd.LstmBatch(g, N)
-ppm, data = gmxo.lstm_synth(N, seed=1, mask=63)
+ppm, data = synth.lstm_records(N, seed=1, mask=63)
 for s in range(S):
     b.ppm[s] = ppm
     b.bytes[s] = data

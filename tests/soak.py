@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Long parity run (not part of the test suite: minutes of CPU oracle time): S streams x T bits through
 the batched surface in chunks, every output and the final state against the oracle.
-  python scripts/soak.py [--shape wide|stock|stock-pairs|single] [--streams 3] [--bits 300000] [--chunk 7000] [--staged 1]"""
+  python tests/soak.py [--shape wide|stock|stock-pairs|single] [--streams 3] [--bits 300000] [--chunk 7000] [--staged 1]"""
 import argparse
 import ctypes as C
 import os
