@@ -27,8 +27,15 @@ def test_bench_line_carries_the_contract(gpu):
     assert d["unit"] == "bits/s" and d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "configs[1]" in d["config"]["workload"] and "model" not in d["config"]
-    assert set(d["also"]) == {"synth3", "stock_held", "stock_real", "stock_fresh", "stock_S1", "indirect", "lstm"}
-    for name, e in [("headline", d)] + list(d["also"].items()):
+    kernels = {"synth3", "stock_held", "stock_real", "stock_fresh", "stock_S1", "single_S1", "indirect", "lstm"}
+    whole = {"e2e_S1", "e2e_S1_mixers", "e2e_S64"}   # the run-ahead compressor on real files (scripts/bench_e2e.py)
+    assert set(d["also"]) == kernels | whole
+    for name in whole:
+        e = d["also"][name]
+        assert "error" not in e, (name, e)
+        assert e["unit"] == "bits/s" and e["value"] > 1e4 and e["identical_to_stock"] is True
+        assert e["config"]["streams"] == (64 if name == "e2e_S64" else 1) and e["cpu_baseline"]["value"] > 1e4
+    for name, e in [("headline", d)] + [(k, d["also"][k]) for k in sorted(kernels)]:
         assert "error" not in e, (name, e)
         ro = e["roofline"]
         assert ro["bound"] == "hbm" and ro["peak"] == 8000.0 and ro["unit"] == "GB/s"
