@@ -56,6 +56,11 @@ struct BatchedOptions {
   bool analysis = true;        // runner-utils.cpp:47
   bool progress = true;        // runner-utils.cpp:59-63
   bool pin_threads = true;     // BatchedCompressFiles: threads onto the cores of the device's NUMA node
+  int max_cpus = -1;           // ... onto at most this many of them.  -1: twice what the container's CPU quota is worth
+                               // (threads spread over every core of the node spend the quota in a burst and are then
+                               // stopped together for the rest of each scheduler period, the device idle meanwhile; a
+                               // thread here waits for its round about half of the time, so twice the quota's cores
+                               // keep inside it -- profiles/r03_exp_cpus.txt); 0: all of the node's
 };
 
 // The cores of the NUMA node the device hangs on (sysfs), or nothing when that cannot be told.
@@ -85,8 +90,25 @@ inline std::vector<int> DeviceNodeCpus(int device) {
   return cpus;
 }
 
-// Keeps the calling thread on those cores that it is allowed on anyway (a container's share); no-op otherwise.
-inline bool PinThreadToDeviceNode(int device) {
+// What the container's CPU quota is worth in cores (cgroup v2 cpu.max, else v1), rounded up; 0: no quota / not known.
+inline int QuotaCpus() {
+  double quota = 0, period = 0;
+  {
+    std::ifstream f("/sys/fs/cgroup/cpu.max");
+    std::string q;
+    if (f >> q >> period && q != "max") quota = atof(q.c_str());
+  }
+  if (quota <= 0) {
+    std::ifstream fq("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), fp("/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+    if (!(fq >> quota) || !(fp >> period)) return 0;
+  }
+  if (quota <= 0 || period <= 0) return 0;
+  return (int)((quota + period - 1) / period);
+}
+
+// Keeps the calling thread on those cores of the device's node that it is allowed on anyway (a container's share), the
+// first max_cpus of them (the node's list names one hardware thread of every core before the second); no-op otherwise.
+inline bool PinThreadToDeviceNode(int device, int max_cpus = 0) {
   const std::vector<int> cpus = DeviceNodeCpus(device);
   if (cpus.empty()) return false;
   cpu_set_t now, want;
@@ -95,7 +117,7 @@ inline bool PinThreadToDeviceNode(int device) {
   if (sched_getaffinity(0, sizeof now, &now) != 0) return false;
   int n = 0;
   for (int c : cpus)
-    if (c < CPU_SETSIZE && CPU_ISSET(c, &now)) {
+    if (c < CPU_SETSIZE && CPU_ISSET(c, &now) && (max_cpus <= 0 || n < max_cpus)) {
       CPU_SET(c, &want);
       ++n;
     }
@@ -336,6 +358,7 @@ struct BatchedStats {
   uint64_t launches = 0;       // chunks of all streams queued on the device
   uint64_t bits = 0;           // bits of all streams mixed there
   int pinned_threads = 0;      // threads kept on the cores of the device's NUMA node
+  int pinned_cpus = 0;         // ... on how many of them (0: all of the node's)
   double submit_seconds = 0;   // host time spent queueing chunks on the device ...
   double wait_seconds = 0;     // ... and waiting for the chunk before (all streams stand still meanwhile)
 };
@@ -356,6 +379,7 @@ inline int BatchedCompressFiles(std::vector<BatchedJob>& jobs, const BatchedOpti
   std::condition_variable start_cv;
   int built = 0, ready = 0;
   std::atomic<int> pinned{0};
+  const int max_cpus = opt.max_cpus < 0 ? 2 * QuotaCpus() : opt.max_cpus;
   using clock = std::chrono::steady_clock;
   const clock::time_point tb = clock::now();
   clock::time_point t0 = tb;
@@ -391,7 +415,7 @@ inline int BatchedCompressFiles(std::vector<BatchedJob>& jobs, const BatchedOpti
         else
           start_cv.wait(lk, [&] { return built == S; });
       }
-      if (opt.pin_threads && PinThreadToDeviceNode(pool.device())) ++pinned;
+      if (opt.pin_threads && PinThreadToDeviceNode(pool.device(), max_cpus)) ++pinned;
       std::unique_ptr<BatchedCompressor> c;
       if (p) {
         c.reset(new BatchedCompressor(p.get(), &data_out, opt));
@@ -432,6 +456,7 @@ inline int BatchedCompressFiles(std::vector<BatchedJob>& jobs, const BatchedOpti
     stats->launches = pool.rounds();
     stats->bits = pool.bits_submitted();
     stats->pinned_threads = pinned.load();
+    stats->pinned_cpus = max_cpus;
     stats->submit_seconds = pool.submit_seconds();
     stats->wait_seconds = pool.wait_seconds();
   }

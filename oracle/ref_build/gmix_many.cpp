@@ -3,7 +3,7 @@
 // Linked by oracle/ref_build/Makefile against the reference's own translation units (feature models, coder,
 // runner-utils) with Predictor::AddMixers constructing gmx::GpuMixer -- the reference calls the product.
 //
-// usage: gmix_many [-T chunk_bits] [-n bytes] [--no-pin] <out dir> <input file>...
+// usage: gmix_many [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] <out dir> <input file>...
 //   each input is compressed to <out dir>/<index>.gmix exactly as `gmix -c` would (runner-utils.cpp:88-121);
 //   -n limits every input to its first n bytes (written to <out dir>/<index>.in first).
 //   One JSON line on stdout: per-file sizes and times, the wall time of the compression phase, bits, launches.
@@ -28,11 +28,13 @@ int main(int argc, char** argv) {
       limit = strtoull(argv[++a], 0, 0);
     else if (!strcmp(argv[a], "--no-pin"))
       opt.pin_threads = false;
+    else if (!strcmp(argv[a], "--cpus") && a + 1 < argc)
+      opt.max_cpus = atoi(argv[++a]);
     else
       break;
   }
   if (argc - a < 2) {
-    fprintf(stderr, "usage: %s [-T chunk_bits] [-n bytes] [--no-pin] <out dir> <input file>...\n", argv[0]);
+    fprintf(stderr, "usage: %s [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] <out dir> <input file>...\n", argv[0]);
     return 2;
   }
   const std::string out_dir = argv[a++];
@@ -56,10 +58,10 @@ int main(int argc, char** argv) {
   const int failed = gmx::BatchedCompressFiles(jobs, opt, &st);
   unsigned long long in_bytes = 0, out_bytes = 0;
   printf("{\"files\": %zu, \"failed\": %d, \"chunk_bits\": %llu, \"wall_seconds\": %.6f, \"build_seconds\": %.3f, "
-         "\"launches\": %llu, \"device_bits\": %llu, \"pinned_threads\": %d, \"submit_seconds\": %.4f, "
+         "\"launches\": %llu, \"device_bits\": %llu, \"pinned_threads\": %d, \"pinned_cpus\": %d, \"submit_seconds\": %.4f, "
          "\"wait_seconds\": %.4f, \"jobs\": [",
          jobs.size(), failed, (unsigned long long)opt.chunk_bits, st.wall_seconds, st.build_seconds,
-         (unsigned long long)st.launches, (unsigned long long)st.bits, st.pinned_threads, st.submit_seconds,
+         (unsigned long long)st.launches, (unsigned long long)st.bits, st.pinned_threads, st.pinned_cpus, st.submit_seconds,
          st.wait_seconds);
   for (size_t k = 0; k < jobs.size(); ++k) {
     printf("%s{\"in\": %llu, \"out\": %llu, \"status\": %d, \"seconds\": %.6f}", k ? ", " : "", jobs[k].input_bytes,

@@ -1,9 +1,12 @@
 #!/bin/bash
-# Kernel timeline of the run-ahead chain for ONE file: where the stages of neighbouring chunks overlap and where they wait.
+# Kernel timeline of the run-ahead chain: where the stages of neighbouring chunks overlap and where they wait.
+#   scripts/trace_chain_timeline.sh [bytes per file = 20000] [chunk bits = 2048] [files = 1]
 cd /root/repo
-W=$(mktemp -d); head -c ${1:-20000} DESIGN.md > $W/f0
+W=$(mktemp -d); mkdir $W/f
+cat DESIGN.md SURVEY.md INTEGRATION.md README.md DESIGN.md SURVEY.md INTEGRATION.md README.md > $W/corpus
+for i in $(seq 0 $((${3:-1}-1))); do tail -c +$((i*1531+1)) $W/corpus | head -c ${1:-20000} > $W/f/$i; done
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $W/prof -o run -- oracle/_ref/gmix_chain_many -T ${2:-2048} $W/out $W/f0 > $W/j.json 2> $W/err
+rocprofv3 --kernel-trace --output-format csv -d $W/prof -o run -- oracle/_ref/gmix_chain_many -T ${2:-2048} $W/out $W/f/* > $W/j.json 2> $W/err
 f=$(find $W/prof -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
@@ -22,6 +25,8 @@ for k, v in by.items():
     gaps = [(v[i + 1][0] - v[i][1]) / 1e6 for i in range(len(v) - 1)]
     mid = slice(len(v) // 4, 3 * len(v) // 4)
     print(f"{k:5s} n={len(v):4d} dur ms avg {sum(d[mid]) / max(1, len(d[mid])):.3f}  gap-to-next ms avg {sum(gaps[mid]) / max(1, len(gaps[mid])):.3f}  period {(v[mid][-1][0] - v[mid][0][0]) / 1e6 / max(1, len(v[mid]) - 1):.3f}")
+ls = [s for s, e in by.get("lstm", [])]
+print("lstm start-to-start ms, in order:", " ".join(f"{(b - a) / 1e6:.1f}" for a, b in zip(ls, ls[1:])))
 print("first rounds (ms since first kernel): kind start end")
 for s, e, k in ev[len(ev) // 2: len(ev) // 2 + 16]: print(f"  {k:5s} {(s - t0) / 1e6:9.3f} {(e - t0) / 1e6:9.3f}")
 PY
