@@ -17,6 +17,9 @@ way (barrier, K steps, max over ranks) with its own roofline and one-core refere
   stock_fresh  the same with every gate context new every bit (worst case)
   stock_S1     ONE stream of the reference's shape: what a single compressor sees
   single_S1    ONE stream of configs[1]'s shape (the 256-step dependent sum: latency, not bandwidth)
+  real_trace   (one GPU) gmx_stock_kernel on the reference Predictor's RECORDED mixer boundary (real inputs, real
+               gate-row changes; the recording is made by oracle/_ref/ref_trace outside the timed region) --
+               scripts/bench_real_trace.py
   indirect     (one GPU) the 41 Indirect models in front of the mixers, 256 streams -- scripts/bench_indirect.py
   lstm         (one GPU) the LSTM byte model, 1024 streams, bytes/s -- scripts/bench_lstm.py
   e2e_S1 / e2e_S1_mixers / e2e_S64   (one GPU) whole files through the run-ahead compressor: the reference's feature
@@ -412,7 +415,8 @@ def main():
             # the 41 Indirect models (bits/s) and the LSTM byte model (bytes/s), each with roofline + cpu_baseline
             # ... and whole files end to end: the reference's feature models and coder on the host running ahead of
             # the device-side models (scripts/bench_e2e.py; every output compared with the stock build's)
-            for name, script, kw in (("indirect", "bench_indirect.py", {}), ("lstm", "bench_lstm.py", {}),
+            for name, script, kw in (("real_trace", "bench_real_trace.py", {}),
+                                     ("indirect", "bench_indirect.py", {}), ("lstm", "bench_lstm.py", {}),
                                      ("e2e_S1", "bench_e2e.py", {"streams": 1, "variant": "chain"}),
                                      ("e2e_S1_mixers", "bench_e2e.py", {"streams": 1, "variant": "mixers"}),
                                      ("e2e_S64", "bench_e2e.py", {"streams": 64, "variant": "chain"})):
@@ -423,7 +427,7 @@ def main():
                     rf = also[name].get("roofline")
                     if rf and rf.get("traffic") is None:   # the committed PMC summary of the same launch shape
                         c = also[name]["config"]
-                        rf.update(pmc_traffic(rf["kernel"], c["streams"], c.get("bits_per_stream_per_step",
+                        rf.update(pmc_traffic(rf["kernel"], c.get("streams", c.get("streams_per_gpu")), c.get("bits_per_stream_per_step",
                                               c.get("bytes_per_stream_per_step")), 0, rf.get("build")))
                 except Exception as e:
                     also[name] = {"error": f"{type(e).__name__}: {e}"}

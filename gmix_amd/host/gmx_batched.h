@@ -228,6 +228,7 @@ class BatchedCompressor : public RunAheadSink {
   // RunAheadSink: a chunk is back
   bool WantsModels() const override { return wants_models_; }
   bool WantsAllOutputs() const override { return wants_all_outputs_; }
+  bool WantsMemoryUsage() const override { return F_ > 0; }  // the rows of analysis/memory.tsv (predictor.cpp:471-504)
   void Drain(const RunAheadView& v) override {
     for (uint64_t i = 0; i < v.n; ++i) {
       enc_.Encode(v.bits[i], v.p[i]);

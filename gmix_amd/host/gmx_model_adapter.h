@@ -113,6 +113,8 @@ struct RunAheadSink {
   virtual void Drain(const RunAheadView& v) = 0;
   virtual bool WantsModels() const { return false; }  // also bring the device-side feature models' predictions back
   virtual bool WantsAllOutputs() const { return false; }  // every mixer's output of every bit (else: the newest bit's)
+  virtual bool WantsMemoryUsage() const { return false; }  // Mixer::GetMemoryUsage will be asked while running ahead: the
+                                                           // bank then counts the rows it has seen on the host, bit by bit
 };
 
 // The device banks of up to n_streams Predictors -- ONE gmx_group, and one gmx_indirect / gmx_lstm where the
@@ -745,10 +747,15 @@ class GpuMixerBank {
       if (!recorded_ || status()) return;  // (a Learn without its Predict has nothing to learn from)
       recorded_ = false;
       s.bits[s.t] = (uint8_t)stm.new_bit;
-      const uint32_t* c = s.ctx + (size_t)s.t * descs_.size();
-      for (size_t j = 0; j < descs_.size(); ++j) {  // Mixer::FindOrCreateMixerData's ++contexts_seen_ (mixer.cpp:39-49)
-        if ((int)j == lstm_ctx_col_) continue;      // (that context is the device's: counted when its chunk returns)
-        MarkSeen(j, c[j]);
+      if (track_seen_) {  // Mixer::FindOrCreateMixerData's ++contexts_seen_ (mixer.cpp:39-49)
+        const uint32_t* c = s.ctx + (size_t)s.t * descs_.size();
+        for (size_t j = 0; j < descs_.size(); ++j) {
+          if ((int)j == lstm_ctx_col_) continue;    // (that context is the device's: counted when its chunk returns)
+          if (!first_mark_ && c[j] == last_ctx_[j]) continue;  // (most contexts stand for a whole byte)
+          last_ctx_[j] = c[j];
+          MarkSeen(j, c[j]);
+        }
+        first_mark_ = false;
       }
       if (++s.t == T_) Flush();
       return;
@@ -792,9 +799,10 @@ class GpuMixerBank {
   }
   unsigned long long MemoryUsage(int index) {
     Settle();
-    if (st().ra)  // mixer.cpp:197-205 from the host's own count of rows (the device runs a chunk behind)
+    if (st().ra && track_seen_)  // mixer.cpp:197-205 from the host's own count of rows (the device runs a chunk behind)
       return 29ull + seen_count_[index] * (unsigned long long)(weight_size_[index] * 4 + 12) +
              8ull * descs_[index].table_size;
+    if (st().ra) SyncRunAhead();  // (a sink that had not asked for it: every chunk home first, then the device's count)
     uint64_t v = 0;
     Call("gmx_bank_memory_usage", [&] { return gmx_bank_memory_usage(group_, slot_, index, &v); });
     return v;
@@ -822,6 +830,8 @@ class GpuMixerBank {
   uint64_t T_ = 0;
   int n_pad_ = 0, mask_words_ = 0, lstm_ctx_col_ = -1;
   std::vector<std::vector<uint64_t>> seen_;
+  std::vector<uint32_t> last_ctx_;   // the context each mixer's row was last marked for
+  bool track_seen_ = false, first_mark_ = true;
   std::vector<uint64_t> seen_count_;
 };
 
@@ -1486,11 +1496,15 @@ inline int GpuMixerBank::BeginRunAhead(RunAheadSink* sink, uint64_t chunk_bits) 
   }
   if (status()) return status();
   lstm_ctx_col_ = mixer_ctx_col;
-  // rows this bank has seen (Mixer::contexts_seen_ / GetMemoryUsage while the device runs behind)
+  // rows this bank has seen (Mixer::contexts_seen_ / GetMemoryUsage while the device runs behind), when the sink
+  // will ask: 33 modulos and bitmap words per bit otherwise spent for nothing
+  track_seen_ = sink && sink->WantsMemoryUsage();
   seen_.assign(descs_.size(), std::vector<uint64_t>());
   seen_count_.assign(descs_.size(), 0);
-  for (size_t j = 0; j < descs_.size(); ++j) seen_[j].assign(((size_t)descs_[j].table_size + 63) / 64, 0);
-  if (ever_ran_) {
+  last_ctx_.assign(descs_.size(), 0);
+  first_mark_ = true;
+  for (size_t j = 0; track_seen_ && j < descs_.size(); ++j) seen_[j].assign(((size_t)descs_[j].table_size + 63) / 64, 0);
+  if (track_seen_ && ever_ran_) {
     Stage();
     for (size_t j = 0; j < descs_.size(); ++j) {
       auto& table = ltm_.mixers[memory_index_[j]].mixer_table;

@@ -23,6 +23,19 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+class _Args:
+    pass
+
+
+def measure(streams=1024, n_bytes=30000, bits=256, launches=24, text=None, staged=-1, prof=False):
+    """The entry bench.py prints under also.real_trace (the recording is made outside the timed region)."""
+    args = _Args()
+    args.streams, args.bytes, args.bits, args.launches = streams, n_bytes, bits, launches
+    args.text = text or os.path.join(ROOT, "SURVEY.md")
+    args.staged, args.prof = staged, prof
+    return _run(args)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=1024)
@@ -32,7 +45,10 @@ def main():
     ap.add_argument("--text", default=os.path.join(ROOT, "SURVEY.md"))
     ap.add_argument("--staged", type=int, default=-1, help="gmx_debug_stock_staged: 1 rows through LDS, 0 lane-private, -1 by stream count")
     ap.add_argument("--prof", action="store_true", help="phase profile (needs GMX_LIB=.../libgmxmix_prof.so)")
-    args = ap.parse_args()
+    print(json.dumps(_run(ap.parse_args())))
+
+
+def _run(args):
     import gmix_amd
     from gmix_amd.bank import Topology
     from trace_common import make_trace
@@ -86,7 +102,25 @@ def main():
     lb, sb = g.export(0)
     steady = ms[2:]
     avg = sum(steady) / len(steady)
+    # algorithmic bytes per bit as bench.py counts them: a row that changes is written back and the new one read
+    # (8 bytes per weight), everything else of the topology's per-bit bytes as it stands
+    ws = topo.weight_sizes()
+    row_bytes = 8 * sum(ws)
+    moved = float(sum(changed[:, j].mean() * 8 * ws[j] for j in range(len(ws))))
+    bytes_per_bit = moved + topo.bytes_per_bit() - row_bytes
+    each = sorted(steady)
     out = {
+        "value": S * T / (avg * 1e-3), "unit": "bits/s", "steps": len(steady), "warmup": 2, "ms_per_step": avg,
+        "config": {"workload": f"{S} streams replaying the reference Predictor's recorded mixer boundary (real feature-model "
+                               f"inputs, real gate-row changes) of {args.bytes} bytes of {os.path.basename(args.text)}",
+                   "n_inputs": topo.n_inputs, "mixers": f"{topo.l0}/{topo.l1}/{1 if topo.has_final else 0}",
+                   "streams_per_gpu": S, "bits_per_stream_per_step": T},
+        "roofline": {"bound": "hbm", "achieved": bytes_per_bit * S * T / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                     "frac": bytes_per_bit * S * T / (avg * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                     "kernel": "gmx_stock_kernel", "kernel_ms_avg": avg, "kernel_ms_min": each[0],
+                     "kernel_ms_median": each[len(each) // 2], "kernel_ms_max": each[-1],
+                     "algorithmic_bytes_per_bit": bytes_per_bit, "bytes_per_launch": bytes_per_bit * S * T,
+                     "build": g.L.gmx_build_info().decode()},
         "workload": f"{S} streams replaying the reference Predictor's recorded mixer boundary of {args.bytes} bytes of "
                     f"{os.path.basename(args.text)} from {S} byte offsets, {T} bits per launch, active masks on",
         "bits_per_s": S * T / (avg * 1e-3), "kernel_ms_avg": avg, "kernel_ms_all": [round(x, 4) for x in ms],
@@ -104,10 +138,10 @@ def main():
         names = ["prefetch issue", "mask + skip", "forward", "logistic + stores", "learn scalars", "update", "commit wait",
                  "evict / adopt / loop"]
         out["phase_cycles_per_bit"] = {n: round(prof[k] / (n_win * T)) for k, n in enumerate(names)}
-    print(json.dumps(out))
     for b in batches:
         b.close()
     g.close()
+    return out
 
 
 if __name__ == "__main__":

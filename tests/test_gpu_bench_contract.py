@@ -29,7 +29,11 @@ def test_bench_line_carries_the_contract(gpu):
     assert "configs[1]" in d["config"]["workload"] and "model" not in d["config"]
     kernels = {"synth3", "stock_held", "stock_real", "stock_fresh", "stock_S1", "single_S1", "indirect", "lstm"}
     whole = {"e2e_S1", "e2e_S1_mixers", "e2e_S64"}   # the run-ahead compressor on real files (scripts/bench_e2e.py)
-    assert set(d["also"]) == kernels | whole
+    assert set(d["also"]) == kernels | whole | {"real_trace"}
+    rt = d["also"]["real_trace"]   # the stock kernel on the reference's recorded mixer boundary
+    assert "error" not in rt, rt
+    assert rt["unit"] == "bits/s" and rt["value"] > 1e7 and rt["stream0_first_window_equals_reference"] is True
+    assert rt["roofline"]["kernel"] == "gmx_stock_kernel" and 0 < rt["roofline"]["frac"] < 1
     for name in whole:
         e = d["also"][name]
         assert "error" not in e, (name, e)
