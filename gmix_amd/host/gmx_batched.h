@@ -185,35 +185,48 @@ class BatchedCompressor : public RunAheadSink {
     return bank_->BeginRunAhead(this, chunk);
   }
   int Code(unsigned long long input_bytes, std::ifstream* is, std::ofstream* os, unsigned long long* output_bytes) {
-    ShortTermMemory& stm = bank_->stm();
-    int rc = GMX_OK;
     const unsigned long long percent = 1 + (input_bytes / 10000);
     if (opt_.progress) {
       fprintf(stderr, "\r                     \r");
       fflush(stderr);
     }
     for (unsigned long long pos = 0; pos < input_bytes && bank_->status() == 0; ++pos) {
-      const char c = is->get();
-      for (int j = 7; j >= 0; --j) {
-        const int bit = (c >> j) & 1;
-        p_->Predict();   // the feature models predict; the mixers record their inputs
-        if (F_ > 0 && stm.bits_seen > 0 && stm.bits_seen % (unsigned long long)kNever == 0) {
-          p_->SetAnalysisFrequency(kNever - 1);  // (never a row of the Predictor's own)
-          p_->Perceive(bit);
-          p_->SetAnalysisFrequency(kNever);
-        } else {
-          p_->Perceive(bit);
-        }
-        if (F_ > 0 && stm.bits_seen % (unsigned long long)F_ == 0 && stm.bits_seen > 0) Capture();
-        ++recorded_;
-        p_->Learn();     // the feature models learn; the mixers record the bit (a full chunk goes to the device)
-      }
+      CodeByte(is->get());
       if (opt_.progress && pos % percent == 0) {
         fprintf(stderr, "\rprogress: %.2f%%", 100.0 * pos / input_bytes);
         fflush(stderr);
       }
     }
-    rc = bank_->EndRunAhead();
+    return Finish(os, output_bytes);
+  }
+  // Code in steps, for a caller with a loop of its own (BatchedRunTraining): eight bits of one byte ...
+  void CodeByte(int c) {
+    ShortTermMemory& stm = bank_->stm();
+    for (int j = 7; j >= 0; --j) {
+      const int bit = (c >> j) & 1;
+      p_->Predict();   // the feature models predict; the mixers record their inputs
+      if (F_ > 0 && stm.bits_seen > 0 && stm.bits_seen % (unsigned long long)kNever == 0) {
+        p_->SetAnalysisFrequency(kNever - 1);  // (never a row of the Predictor's own)
+        p_->Perceive(bit);
+        p_->SetAnalysisFrequency(kNever);
+      } else {
+        p_->Perceive(bit);
+      }
+      if (F_ > 0 && stm.bits_seen % (unsigned long long)F_ == 0 && stm.bits_seen > 0) Capture();
+      ++recorded_;
+      p_->Learn();     // the feature models learn; the mixers record the bit (a full chunk goes to the device)
+    }
+  }
+  // ... every bit handed in so far coded and every result home, run-ahead mode kept (the Predictor can then be copied
+  // or written out, and what was asked to be summed is whole) ...
+  int Sync() {
+    int rc = bank_->SyncRunAhead();
+    return rc ? rc : bank_->status();
+  }
+  // ... and the end: run-ahead mode left, the coder flushed
+  int Finish(std::ofstream* os, unsigned long long* output_bytes) {
+    ShortTermMemory& stm = bank_->stm();
+    int rc = bank_->EndRunAhead();
     if (rc == GMX_OK) rc = bank_->status();
     if (F_ > 0) {
       for (const Source& src : on_device_) stm.entropy[analysed_[src.column]] = src.ema;
@@ -224,6 +237,9 @@ class BatchedCompressor : public RunAheadSink {
     *output_bytes = os->tellp();
     return GMX_OK;
   }
+  // Adds log2 of the probability given to every coded bit, in bit order (RunTraining's train_entropy,
+  // runner-utils.cpp:276-279), as the chunks come back.
+  void SumLog2Into(double* sum) { log2_sum_ = sum; }
 
   // RunAheadSink: a chunk is back
   bool WantsModels() const override { return wants_models_; }
@@ -232,6 +248,13 @@ class BatchedCompressor : public RunAheadSink {
   void Drain(const RunAheadView& v) override {
     for (uint64_t i = 0; i < v.n; ++i) {
       enc_.Encode(v.bits[i], v.p[i]);
+      if (log2_sum_) {  // (the reference's own expression, float in, whatever log2 this translation unit sees)
+        const float prob = v.p[i];
+        if (v.bits[i])
+          *log2_sum_ += log2(prob);
+        else
+          *log2_sum_ += log2(1 - prob);
+      }
       if (F_ > 0) {
         for (Source& src : on_device_) {  // Predictor::UpdateEntropy (predictor.cpp:439-469) on what the device produced
           float x;
@@ -335,7 +358,135 @@ class BatchedCompressor : public RunAheadSink {
   bool wants_models_ = false, wants_all_outputs_ = false;
   std::deque<Row> rows_;
   uint64_t recorded_ = 0, drained_ = 0;
+  double* log2_sum_ = nullptr;
 };
+
+// A Predictor that is only scored on bytes it learns from (the test pass of runner_utils::RunTraining,
+// runner-utils.cpp:291-306: Predict / Perceive / Learn of every bit and the sum of log2 p, no coder).
+class BatchedScorer : public RunAheadSink {
+ public:
+  BatchedScorer(Predictor* p, const BatchedOptions& opt) : p_(p), opt_(opt), bank_(GpuMixerBank::Of(p, sizeof(Predictor))) {}
+  int Begin() {
+    if (!bank_) return GMX_ERR_INVALID;
+    const uint64_t chunk = opt_.chunk_bits < 8 ? 8 : opt_.chunk_bits & ~7ull;
+    return bank_->BeginRunAhead(this, chunk);
+  }
+  void ScoreByte(int c) {
+    for (int j = 7; j >= 0; --j) {
+      p_->Predict();
+      p_->Perceive((c >> j) & 1);
+      p_->Learn();
+    }
+  }
+  int End() {
+    int rc = bank_->EndRunAhead();
+    return rc ? rc : bank_->status();
+  }
+  int status() const { return bank_ ? bank_->status() : GMX_ERR_INVALID; }
+  double log2_sum() const { return sum_; }
+  void Drain(const RunAheadView& v) override {
+    for (uint64_t i = 0; i < v.n; ++i) {
+      const float prob = v.p[i];
+      if (v.bits[i])
+        sum_ += log2(prob);
+      else
+        sum_ += log2(1 - prob);
+    }
+  }
+
+ private:
+  Predictor* p_;
+  BatchedOptions opt_;
+  std::shared_ptr<GpuMixerBank> bank_;
+  double sum_ = 0;
+};
+
+// runner_utils::RunTraining (runner-utils.cpp:222-322), argument for argument, with the device-side models of both
+// Predictors -- the one that trains and the copy that is scored on the test file every other per cent -- running
+// ahead: same data/tmp, analysis/*.tsv, data/trained_checkpoint and printed cross entropy.
+inline bool BatchedRunTraining(const std::string& checkpoint_path, const std::string& train_path,
+                               const std::string& test_path, unsigned long long* input_bytes,
+                               unsigned long long* output_bytes, const BatchedOptions& opt_in = BatchedOptions()) {
+  std::ifstream data_train(train_path, std::ios::in | std::ios::binary);
+  if (!data_train.is_open()) {
+    printf("Can not open: %s\n", train_path.c_str());
+    return false;
+  }
+  std::ifstream data_test(test_path, std::ios::in | std::ios::binary);
+  if (!data_test.is_open()) {
+    printf("Can not open: %s\n", test_path.c_str());
+    return false;
+  }
+  data_train.seekg(0, std::ios::end);
+  *input_bytes = data_train.tellg();
+  data_train.seekg(0, std::ios::beg);
+  data_test.seekg(0, std::ios::end);
+  const unsigned long long test_bytes = data_test.tellg();
+  data_test.seekg(0, std::ios::beg);
+
+  std::filesystem::create_directory("analysis");
+  std::ofstream metrics("analysis/training.tsv", std::ios::out);
+  metrics << "bytes\ttrain_entropy\ttest_entropy" << std::endl;
+  std::filesystem::create_directory("data");
+  std::ofstream data_out("data/tmp", std::ios::out | std::ios::binary);
+  if (!data_out.is_open()) {
+    printf("Can not open: data/tmp\n");
+    return false;
+  }
+  runner_utils::WriteHeader(*input_bytes, &data_out);
+
+  Predictor p;
+  if (!checkpoint_path.empty()) {
+    printf("\rLoading checkpoint...");
+    fflush(stdout);
+    p.ReadCheckpoint(checkpoint_path);
+    printf("\r                        ");
+  }
+  BatchedOptions opt = opt_in;
+  opt.analysis = true;   // p.EnableAnalysis(8 * input_bytes / 1000), runner-utils.cpp:270
+  opt.progress = false;  // (this loop prints its own)
+  if (const char* e = getenv("GMX_CHUNK_BITS")) opt.chunk_bits = strtoull(e, nullptr, 0);  // (tests: many small chunks)
+  BatchedCompressor trainer(&p, &data_out, opt);
+  double train_entropy = 0;
+  trainer.SumLog2Into(&train_entropy);
+  int rc = trainer.Begin(*input_bytes);
+  const unsigned long long percent = 1 + ((*input_bytes) / 100);
+  for (unsigned int pos = 0; rc == GMX_OK && pos < *input_bytes; ++pos) {
+    trainer.CodeByte(data_train.get());
+    if (pos % percent == 0) {
+      printf("\rtraining: %lld%%", pos / percent);
+      fflush(stdout);
+      if (pos == 0) continue;
+      if ((pos / percent % 2) != 0) continue;
+      rc = trainer.Sync();  // train_entropy is whole up to this byte, and the Predictor can be copied
+      if (rc) break;
+      Predictor p2;
+      p2.Copy(p);
+      BatchedOptions quiet = opt;
+      quiet.analysis = false;
+      BatchedScorer scorer(&p2, quiet);
+      rc = scorer.Begin();
+      data_test.seekg(0, std::ios::beg);
+      for (unsigned int pos2 = 0; rc == GMX_OK && pos2 < test_bytes; ++pos2) {
+        scorer.ScoreByte(data_test.get());
+        rc = scorer.status();
+      }
+      if (rc == GMX_OK) rc = scorer.End();
+      const double test_entropy = scorer.log2_sum();
+      metrics << std::fixed << std::setprecision(5) << pos << "\t" << -train_entropy / pos << "\t"
+              << -test_entropy / test_bytes << std::endl;
+    }
+  }
+  if (rc == GMX_OK) rc = trainer.Finish(&data_out, output_bytes);
+  if (rc) {
+    fprintf(stderr, "\ngmx::BatchedRunTraining: %s (status %d)\n", gmx_strerror(rc), rc);
+    return false;
+  }
+  train_entropy = -train_entropy / *input_bytes;
+  printf("\rtraining cross entropy: %.4f\n", train_entropy);
+  p.WriteCheckpoint("data/trained_checkpoint");
+  return true;
+}
 
 // runner_utils::Compress (runner-utils.cpp:43-67), argument for argument; returns 0 or a gmx_status.
 inline int BatchedCompress(unsigned long long input_bytes, std::ifstream* is, std::ofstream* os,

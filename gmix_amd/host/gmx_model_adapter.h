@@ -1484,7 +1484,9 @@ inline int GpuMixerBank::BeginRunAhead(RunAheadSink* sink, uint64_t chunk_bits) 
   if (s.lstm) {
     // the run-ahead LSTM works on whole bytes, and hands over what hangs on ShortTermMemory::lstm_prediction_context:
     // a gate context of the mixers (predictor.cpp:321) and the context of one Indirect model (predictor.cpp:117-119)
-    if (stm_.recent_bits != 1 && stm_.bits_seen > 0) return GMX_ERR_STATE;
+    // (between a byte's last Learn and the next Predict recent_bits still holds the byte's first seven bits,
+    // basic-contexts.cpp:27-33: the blackboard runs a bit behind)
+    if (!(stm_.recent_bits >= 128 || (stm_.recent_bits == 1 && stm_.bits_seen == 0))) return GMX_ERR_STATE;
     s.lstm->Settle();
     parts |= MixerPool::kLstm;
     lstm_slot = s.lstm->prediction_index();

@@ -8,7 +8,7 @@ import os
 
 import pytest
 
-from batched_common import REF, compress_pair, corpus, gmix, need, run_many, same_outputs
+from batched_common import REF, compress_pair, corpus, gmix, need, run_many, same_outputs, same_training, train_pair
 from dropin_common import checkpoint_after_batches, compare, run_all, same_checkpoint
 
 
@@ -74,3 +74,14 @@ def test_state_left_behind_equals_the_per_bit_loop(tmp_path, exe, chunk):
     (stock,) = run_all([("ref_tester_strict", 0)], 1200, tmp_path)
     ck = checkpoint_after_batches(exe, stock, 1200, chunk, tmp_path)
     same_checkpoint(os.path.join(stock, "restart"), ck)
+
+
+@pytest.mark.parametrize("exe", ["gmix_batched_shim", "gmix_chain_batched_shim"])
+def test_training_cli_equals_stock(tmp_path, exe):
+    """`gmix -t`: runner_utils::RunTraining answered by gmx::BatchedRunTraining.  24 training bytes in chunks of 40
+    bits, the Predictor synced, copied (Predictor::Copy out of a bank that runs ahead) and the copy scored on 64 test
+    bytes, running ahead as well, eleven times; then Predictor::WriteCheckpoint.  (Small: a Predictor is built per
+    evaluation, and that is seconds here.)"""
+    _skip_unless("gmix_strict", exe)
+    stock, batched = train_pair("gmix_strict", exe, corpus(24, 100), corpus(64, 3000), tmp_path, env={"GMX_CHUNK_BITS": "40"})
+    same_training(stock, batched)
