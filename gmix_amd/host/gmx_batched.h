@@ -242,7 +242,8 @@ class BatchedCompressor : public RunAheadSink {
   void SumLog2Into(double* sum) { log2_sum_ = sum; }
 
   // RunAheadSink: a chunk is back
-  bool WantsModels() const override { return wants_models_; }
+  bool WantsModels() const override { return wants_models_ || F_ > 0; }  // (with analysis on at least the last bit's flags)
+  bool SilentSlotsAreZero() const override { return F_ > 0; }
   bool WantsAllOutputs() const override { return wants_all_outputs_; }
   bool WantsMemoryUsage() const override { return F_ > 0; }  // the rows of analysis/memory.tsv (predictor.cpp:471-504)
   void Drain(const RunAheadView& v) override {

@@ -113,6 +113,9 @@ struct RunAheadSink {
   virtual void Drain(const RunAheadView& v) = 0;
   virtual bool WantsModels() const { return false; }  // also bring the device-side feature models' predictions back
   virtual bool WantsAllOutputs() const { return false; }  // every mixer's output of every bit (else: the newest bit's)
+  // Predictor::Predict clears the blackboard's predictions before the models run when analysis is on
+  // (predictor.cpp:362-365): a device-side model that stays silent then leaves 0 in its slot, not its last value
+  virtual bool SilentSlotsAreZero() const { return false; }
   virtual bool WantsMemoryUsage() const { return false; }  // Mixer::GetMemoryUsage will be asked while running ahead: the
                                                            // bank then counts the rows it has seen on the host, bit by bit
 };
@@ -831,6 +834,7 @@ class GpuMixerBank {
   int n_pad_ = 0, mask_words_ = 0, lstm_ctx_col_ = -1;
   std::vector<std::vector<uint64_t>> seen_;
   std::vector<uint32_t> last_ctx_;   // the context each mixer's row was last marked for
+  std::vector<uint8_t> last_ind_active_;  // the Indirect models' active flags of the newest bit that came back
   bool track_seen_ = false, first_mark_ = true;
   std::vector<uint64_t> seen_count_;
 };
@@ -1531,7 +1535,14 @@ inline int GpuMixerBank::BeginRunAhead(RunAheadSink* sink, uint64_t chunk_bits) 
 }
 
 inline int GpuMixerBank::SlotsHome() {
-  if (st().indirect) st().indirect->SlotsFromDevice(stm_);
+  GpuIndirectBank* ib = st().indirect;
+  if (!ib) return status();
+  ib->SlotsFromDevice(stm_);
+  if (sink_ && sink_->SilentSlotsAreZero() && last_ind_active_.size() == 2 * ib->descs_.size())
+    for (size_t i = 0; i < ib->descs_.size(); ++i) {
+      if (!last_ind_active_[2 * i]) stm_.predictions[ib->descs_[i].slot_indirect] = 0;  // (silent, or a zero logit)
+      if (!last_ind_active_[2 * i + 1]) stm_.predictions[ib->descs_[i].slot_run_map] = 0;
+    }
   return status();
 }
 
@@ -1548,11 +1559,14 @@ inline int GpuMixerBank::Flush() {
     for (int k = 0; k < stm_.num_layer0_mixers; ++k) stm_.mixer_layer0_outputs[k] = o[j++];
     for (int k = 0; k < stm_.num_layer1_mixers; ++k) stm_.mixer_layer1_outputs[k] = o[j++];
     if (j < (size_t)M) stm_.final_mixer_output = o[j];
+    if (v.ind_active) last_ind_active_.assign(v.ind_active + (v.n - 1) * 2 * (size_t)v.n_ind, v.ind_active + v.n * 2 * (size_t)v.n_ind);
     if (st().lstm) {
       st().lstm->range_on_device_ = true;
       // lstm-model.cpp:25-33: what the newest byte's LstmModel::Predict left on the blackboard
       if (v.lstm_context && v.n >= 8) stm_.lstm_prediction_context = v.lstm_context[v.n / 8 - 1];
-      if (v.lstm_pred) stm_.predictions[st().lstm->prediction_index()] = v.lstm_pred[v.n - 1];  // (a silent bit repeats the slot)
+      if (v.lstm_pred)  // (a silent bit repeats the slot -- or leaves the zero Predictor::Predict put there)
+        stm_.predictions[st().lstm->prediction_index()] =
+            (sink_ && sink_->SilentSlotsAreZero() && !v.lstm_active[v.n - 1]) ? 0.0f : v.lstm_pred[v.n - 1];
     }
   }
   return GMX_OK;

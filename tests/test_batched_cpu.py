@@ -85,3 +85,15 @@ def test_training_cli_equals_stock(tmp_path, exe):
     _skip_unless("gmix_strict", exe)
     stock, batched = train_pair("gmix_strict", exe, corpus(24, 100), corpus(64, 3000), tmp_path, env={"GMX_CHUNK_BITS": "40"})
     same_training(stock, batched)
+
+
+@pytest.mark.slow
+def test_training_with_analysis_rows_equals_stock(tmp_path):
+    """The same with the analysis sampling on (130 training bytes: a row per bit): Predictor::Predict then clears the
+    blackboard's predictions before the models run (predictor.cpp:362-365), so a device-side model that stayed silent
+    at the last bit leaves 0 in the checkpoint, not its last value; the averages of the device-side models go back into
+    ShortTermMemory::entropy."""
+    _skip_unless("gmix_strict", "gmix_chain_batched_shim")
+    stock, batched = train_pair("gmix_strict", "gmix_chain_batched_shim", corpus(130, 100), corpus(16, 3000), tmp_path,
+                                env={"GMX_CHUNK_BITS": "72"})
+    same_training(stock, batched)
