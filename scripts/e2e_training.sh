@@ -10,7 +10,7 @@ head -c $N $W/corpus > $W/train
 tail -c $M $W/corpus > $W/test
 {
 echo "host: $(grep -m1 'model name' /proc/cpuinfo | cut -d: -f2); train $N bytes, test $M bytes (scored by a copy of the Predictor every other per cent: 49 times)"
-for exe in gmix_strict gmix_fast gmix_batched gmix_chain_batched; do
+for exe in ${EXES:-gmix_strict gmix_fast gmix_batched gmix_chain_batched}; do
   mkdir -p $W/$exe; cd $W/$exe
   s=$(date +%s.%N); $REF/$exe -t $W/train $W/test > log 2>&1; rc=$?; e=$(date +%s.%N)
   cd - > /dev/null
