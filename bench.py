@@ -25,6 +25,8 @@ way (barrier, K steps, max over ranks) with its own roofline and one-core refere
   e2e_S1 / e2e_S1_mixers / e2e_S64   (one GPU) whole files through the run-ahead compressor: the reference's feature
                models and coder on the host cores, LSTM + Indirect models + mixers (or the mixers alone) on the device in
                double-buffered batches; 1 file and 64 files side by side -- scripts/bench_e2e.py
+  e2e_train    (one GPU) `gmix -t` (runner_utils::RunTraining) the same way: training Predictor and scored copy
+               running ahead -- scripts/bench_e2e.py measure_training()
 (--no-also leaves them out; --config X makes X the headline workload for profiling.)
 
 N > 1: one rank per GPU over RCCL.  Under torch.distributed.run the ranks come from the environment;
@@ -419,9 +421,11 @@ def main():
                                      ("indirect", "bench_indirect.py", {}), ("lstm", "bench_lstm.py", {}),
                                      ("e2e_S1", "bench_e2e.py", {"streams": 1, "variant": "chain"}),
                                      ("e2e_S1_mixers", "bench_e2e.py", {"streams": 1, "variant": "mixers"}),
-                                     ("e2e_S64", "bench_e2e.py", {"streams": 64, "variant": "chain"})):
+                                     ("e2e_S64", "bench_e2e.py", {"streams": 64, "variant": "chain"}),
+                                     ("e2e_train", "bench_e2e.py", {"training": True})):
                 try:
-                    also[name] = aux_bench(script).measure(**kw)
+                    mod = aux_bench(script)
+                    also[name] = mod.measure_training() if kw.get("training") else mod.measure(**kw)
                     if args.no_cpu_baseline:
                         also[name].pop("cpu_baseline", None)
                     rf = also[name].get("roofline")

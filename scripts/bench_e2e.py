@@ -128,6 +128,61 @@ def measure(streams=1, n_bytes=30000, variant="chain", chunk=2048, verify=True, 
     return out
 
 
+def measure_training(train_bytes=20000, test_bytes=4000, variant="chain", verify=True, cpu=True):
+    """`gmix -t train test` (runner_utils::RunTraining, runner-utils.cpp:222-322): the training Predictor and the copy
+    scored on the test file every other per cent both run ahead of the device (gmx::BatchedRunTraining).  `value` =
+    bits through a Predictor (training bits + 49 x the test bits) / wall time of the whole CLI -- the 1 + 49
+    constructions and copies of a Predictor, which are the reference's own host work, included.  cpu_baseline = the
+    reference's -Ofast CLI doing the same; identical_to_stock = data/tmp, analysis/training.tsv and
+    data/trained_checkpoint.long against the strict build's."""
+    exe = {"chain": "gmix_chain_batched", "mixers": "gmix_batched"}[variant]
+    for e in (exe,):
+        if not os.path.exists(os.path.join(REF, e)):
+            raise RuntimeError(f"oracle/_ref/{e} missing (make -C oracle/ref_build batched, needs /root/reference)")
+    with tempfile.TemporaryDirectory() as tmp:
+        train, src = corpus(train_bytes, 500)
+        test, _ = corpus(test_bytes, 90000)
+        open(os.path.join(tmp, "train"), "wb").write(train)
+        open(os.path.join(tmp, "test"), "wb").write(test)
+
+        def run(e):
+            d = os.path.join(tmp, e)
+            os.mkdir(d)
+            t0 = time.perf_counter()
+            r = subprocess.run([os.path.join(REF, e), "-t", os.path.join(tmp, "train"), os.path.join(tmp, "test")], cwd=d,
+                               capture_output=True, text=True, timeout=1500)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0 or "training cross entropy" not in r.stdout:
+                raise RuntimeError(f"{e} -t failed: {r.stdout[-300:]} {r.stderr[-500:]}")
+            return dt, r.stdout[r.stdout.index("training cross entropy"):].splitlines()[0]
+
+        dt, said = run(exe)
+        percent = 1 + train_bytes // 100
+        evals = sum(1 for pos in range(1, train_bytes) if pos % percent == 0 and (pos // percent) % 2 == 0)
+        bits = 8 * (train_bytes + evals * test_bytes)
+        out = {"metric": "training bits/sec (`gmix -t`: a Predictor trained on one file and a copy of it scored on a test "
+                         "file every other per cent, device-side models in run-ahead batches)",
+               "value": bits / dt, "unit": "bits/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f32", "data": "real text",
+               "config": {"workload": f"gmix -t: {train_bytes} training bytes, {test_bytes} test bytes scored {evals} times, of {src}",
+                          "streams": 1, "train_bytes": train_bytes, "test_bytes": test_bytes, "evaluations": evals,
+                          "variant": variant, "host_cpu": host_cpu(), "cpu_quota_cores": cpu_quota()},
+               "seconds": dt, "bits": bits, "printed": said}
+        others = [e for e, want in (("gmix_strict", verify), ("gmix_fast", cpu)) if want and os.path.exists(os.path.join(REF, e))]
+        with ThreadPoolExecutor(max(1, len(others))) as ex:
+            res = dict(zip(others, ex.map(run, others)))
+        if "gmix_strict" in res:
+            same = res["gmix_strict"][1] == said
+            for f in ("data/tmp", "analysis/training.tsv", "data/trained_checkpoint.long"):
+                same = same and open(os.path.join(tmp, "gmix_strict", f), "rb").read() == open(os.path.join(tmp, exe, f), "rb").read()
+            out["identical_to_stock"] = same
+        if "gmix_fast" in res:
+            out["cpu_baseline"] = {"value": bits / res["gmix_fast"][0], "unit": "bits/s", "cores": 1, "kind": "reference",
+                                   "sample": f"the reference's own `gmix -t` on the same two files, -Ofast -march=x86-64-v3 (the "
+                                             f"makefile's flags with a portable -march, not native), {res['gmix_fast'][0]:.1f} s"
+                                             + (", run beside the strict build's" if len(others) > 1 else "")}
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=1)

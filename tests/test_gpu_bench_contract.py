@@ -28,7 +28,7 @@ def test_bench_line_carries_the_contract(gpu):
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "configs[1]" in d["config"]["workload"] and "model" not in d["config"]
     kernels = {"synth3", "stock_held", "stock_real", "stock_fresh", "stock_S1", "single_S1", "indirect", "lstm"}
-    whole = {"e2e_S1", "e2e_S1_mixers", "e2e_S64"}   # the run-ahead compressor on real files (scripts/bench_e2e.py)
+    whole = {"e2e_S1", "e2e_S1_mixers", "e2e_S64", "e2e_train"}   # the run-ahead compressor / trainer on real files (scripts/bench_e2e.py)
     assert set(d["also"]) == kernels | whole | {"real_trace"}
     rt = d["also"]["real_trace"]   # the stock kernel on the reference's recorded mixer boundary
     assert "error" not in rt, rt
@@ -39,6 +39,7 @@ def test_bench_line_carries_the_contract(gpu):
         assert "error" not in e, (name, e)
         assert e["unit"] == "bits/s" and e["value"] > 1e4 and e["identical_to_stock"] is True
         assert e["config"]["streams"] == (64 if name == "e2e_S64" else 1) and e["cpu_baseline"]["value"] > 1e4
+    assert d["also"]["e2e_train"]["config"]["evaluations"] >= 40
     for name, e in [("headline", d)] + [(k, d["also"][k]) for k in sorted(kernels)]:
         assert "error" not in e, (name, e)
         ro = e["roofline"]
