@@ -9,7 +9,10 @@
 //                              run, the mixers (gmx::GpuMixer in run-ahead mode, gmx_model_adapter.h) only record
 //                              {predictions, active_models, 33 contexts, bit} into the pinned arrays of a gmx_batch
 //     device, bits t-T .. t    gmx_batch_upload / gmx_group_run / gmx_batch_download on the chunk recorded before
-//                              (two batches used alternately: BASELINE configs[3]'s double-buffered batches)
+//                              (a ring of three batches, MixerPool::kRing: BASELINE configs[3]'s double-buffered
+//                              batches with one more in flight) -- and, when the Predictor's Indirect models and LSTM
+//                              are gmx::GpuIndirect / gmx::GpuLstmModel too, gmx_lstm_run -> gmx_lstm_feed ->
+//                              gmx_indirect_run(into) in front of it, each bank on a stream of its own
 //     host, bits t-2T .. t-T   Encoder::Encode (coder/encoder.cpp:10-25) drains the probabilities that came back
 //
 // Same Predictor, same feature models, same coder, same bytes as `gmix -c` -- tests/test_gpu_batched.py compares
@@ -31,6 +34,9 @@
 //
 // Many files: BatchedCompressFiles runs one Predictor per file on a thread of its own, all mixers in ONE gmx_group
 // (gmx::MixerPool), one launch per chunk for all files.
+//
+// Training (`gmix -t`, runner_utils::RunTraining, runner-utils.cpp:222-322) knows its bits as well:
+// BatchedRunTraining, on BatchedCompressor's steps (Begin / CodeByte / Sync / Finish) and BatchedScorer.
 #ifndef GMX_BATCHED_H_
 #define GMX_BATCHED_H_
 
@@ -106,8 +112,10 @@ inline int QuotaCpus() {
   return (int)((quota + period - 1) / period);
 }
 
-// Keeps the calling thread on those cores of the device's node that it is allowed on anyway (a container's share), the
-// first max_cpus of them (the node's list names one hardware thread of every core before the second); no-op otherwise.
+// Keeps the calling thread on those cores of the device's node that it is allowed on anyway (a container's share) -- on
+// max_cpus of them when that is given: a window of the node's list (which names one hardware thread of every core
+// before the second) that starts device * max_cpus in, so that processes driving other devices of the same node take
+// other cores.  No-op when sysfs does not say.
 inline bool PinThreadToDeviceNode(int device, int max_cpus = 0) {
   const std::vector<int> cpus = DeviceNodeCpus(device);
   if (cpus.empty()) return false;
@@ -115,13 +123,14 @@ inline bool PinThreadToDeviceNode(int device, int max_cpus = 0) {
   CPU_ZERO(&now);
   CPU_ZERO(&want);
   if (sched_getaffinity(0, sizeof now, &now) != 0) return false;
-  int n = 0;
+  std::vector<int> allowed;
   for (int c : cpus)
-    if (c < CPU_SETSIZE && CPU_ISSET(c, &now) && (max_cpus <= 0 || n < max_cpus)) {
-      CPU_SET(c, &want);
-      ++n;
-    }
-  return n > 0 && sched_setaffinity(0, sizeof want, &want) == 0;
+    if (c < CPU_SETSIZE && CPU_ISSET(c, &now)) allowed.push_back(c);
+  if (allowed.empty()) return false;
+  const size_t n = allowed.size(), k = (max_cpus <= 0 || (size_t)max_cpus > n) ? n : (size_t)max_cpus;
+  const size_t first = ((size_t)(device < 0 ? 0 : device) * k) % n;
+  for (size_t i = 0; i < k; ++i) CPU_SET(allowed[(first + i) % n], &want);
+  return sched_setaffinity(0, sizeof want, &want) == 0;
 }
 
 // One stream's compression: the loop of runner_utils::Compress, the coder behind the device.
