@@ -11,7 +11,7 @@ python3 scripts/pmc_summary.py stock_fresh $R gmx_stock_kernel 1024 1024 22072 "
 python3 scripts/pmc_summary.py indirect $R gmx_indirect_kernel 256 4096 743 "python scripts/bench_indirect.py" 0 > /dev/null
 python3 scripts/pmc_summary.py lstm $R gmx_lstm_kernel 1024 200 452356 "python scripts/bench_lstm.py" 0 > /dev/null
 python3 scripts/pmc_summary.py stock_S1 $R gmx_stock_kernel 1 8192 3193 "python bench.py --config stock_S1 --steps 4 $S" 2 > /dev/null
-for f in e2e.txt many_scaling.txt; do [ -f gpurun_out/$f ] && cp gpurun_out/$f profiles/r$(printf %02d $R)_$f; done
+for f in e2e.txt many_scaling.txt many_chain.txt timeline_S1.txt timeline_S64.txt lstm_phase_profile.txt; do [ -f gpurun_out/$f ] && cp gpurun_out/$f profiles/r$(printf %02d $R)_$f; done
 for f in lstm_bench pipeline_bench; do [ -s gpurun_out/$f.json ] && cp gpurun_out/$f.json profiles/r$(printf %02d $R)_$f.json; done
 [ -s gpurun_out/bench_default.json ] && cp gpurun_out/bench_default.json profiles/r$(printf %02d $R)_bench_default.json
 cp gpurun_out/indirect_bench.json profiles/r$(printf %02d $R)_indirect_bench.json
