@@ -429,7 +429,7 @@ def main():
                     if args.no_cpu_baseline:
                         also[name].pop("cpu_baseline", None)
                     rf = also[name].get("roofline")
-                    if rf and rf.get("traffic") is None:   # the committed PMC summary of the same launch shape
+                    if rf and rf.get("traffic") is None and name in ("indirect", "lstm"):   # the committed PMC summary of the same launch shape
                         c = also[name]["config"]
                         rf.update(pmc_traffic(rf["kernel"], c.get("streams", c.get("streams_per_gpu")), c.get("bits_per_stream_per_step",
                                               c.get("bytes_per_stream_per_step")), 0, rf.get("build")))
