@@ -106,13 +106,14 @@ def test_state_left_behind_equals_the_per_bit_loop(gpu, tmp_path):
         same_checkpoint(os.path.join(stock, "restart"), checkpoint_after_batches(exe, stock, 40000, chunk, tmp_path))
 
 
-@pytest.mark.parametrize("exe", ["gmix_batched", "gmix_chain_batched"])
+@pytest.mark.parametrize("exe", ["gmix_chain_batched"])   # (the mixers-only build: tests/test_batched_cpu.py, on the shim)
 def test_training_cli_equals_stock_and_resumes_from_its_checkpoint(gpu, tmp_path, exe):
     """`gmix -t train test` (runner_utils::RunTraining -> gmx::BatchedRunTraining): 20 000 training bytes running
     ahead, every other per cent the Predictor synced, copied and the copy scored on 1 000 test bytes (running ahead
     too, in a pool of its own); data/tmp, analysis/training.tsv, both analysis tables, the printed cross entropy and
     data/trained_checkpoint equal the stock build's.  Then `gmix -t checkpoint train2 test` from that checkpoint
-    (Predictor::ReadCheckpoint into banks that then run ahead) -- the same again."""
+    (Predictor::ReadCheckpoint into banks that then run ahead; 40 bytes, 19 evaluations: a Predictor is built for each,
+    and that is what a training run's time is made of at these sizes) -- the same again."""
     need("gmix_strict", exe)
     a = tmp_path / "first"
     a.mkdir()
@@ -121,5 +122,5 @@ def test_training_cli_equals_stock_and_resumes_from_its_checkpoint(gpu, tmp_path
     b = tmp_path / "second"
     b.mkdir()
     cps = [stock / "data" / "trained_checkpoint", batched / "data" / "trained_checkpoint"]
-    stock2, batched2 = train_pair("gmix_strict", exe, corpus(6000, 40000), corpus(1000, 90000), b, checkpoints=cps)
+    stock2, batched2 = train_pair("gmix_strict", exe, corpus(40, 40000), corpus(1000, 90000), b, checkpoints=cps)
     same_training(stock2, batched2)
