@@ -333,6 +333,9 @@ def main():
                     help="--config stock*: the lane-pair kernel (gmx_wide.hip) instead of the generated streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="only the headline workload")
+    ap.add_argument("--e2e-bytes", type=int, default=30000, help="bytes per file of the also.e2e_* entries")
+    ap.add_argument("--train-bytes", type=int, default=20000, help="also.e2e_train: training file (a test run shrinks it)")
+    ap.add_argument("--test-bytes", type=int, default=4000, help="also.e2e_train: test file")
     ap.add_argument("--rehearse-cpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-sample-bits", type=int, default=None,
                     help="bits of the same stream for the one-core reference (default: about 5-15 s of CPU work)")
@@ -425,7 +428,12 @@ def main():
                                      ("e2e_train", "bench_e2e.py", {"training": True})):
                 try:
                     mod = aux_bench(script)
-                    also[name] = mod.measure_training() if kw.get("training") else mod.measure(**kw)
+                    if kw.get("training"):
+                        also[name] = mod.measure_training(train_bytes=args.train_bytes, test_bytes=args.test_bytes)
+                    elif script == "bench_e2e.py":
+                        also[name] = mod.measure(n_bytes=args.e2e_bytes, **kw)
+                    else:
+                        also[name] = mod.measure(**kw)
                     if args.no_cpu_baseline:
                         also[name].pop("cpu_baseline", None)
                     rf = also[name].get("roofline")

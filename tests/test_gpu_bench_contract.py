@@ -1,5 +1,6 @@
 """bench.py's one JSON line: the driver's contract fields, `roofline`, `cpu_baseline`, and under `also`
-the north_star's other shapes -- on a reduced headline size so that the test takes half a minute."""
+the north_star's other shapes -- on reduced sizes (headline launch, end-to-end files, training file) so that the test
+takes a minute or two."""
 import json
 import os
 import subprocess
@@ -16,7 +17,8 @@ def test_bench_line_carries_the_contract(gpu):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--streams", "1024", "--bits", "256", "--steps", "4",
-                        "--cpu-sample-bits", "200000"], env=env, capture_output=True, text=True, timeout=900)
+                        "--cpu-sample-bits", "200000", "--e2e-bytes", "8000", "--train-bytes", "30", "--test-bytes", "500"],
+                       env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -39,7 +41,7 @@ def test_bench_line_carries_the_contract(gpu):
         assert "error" not in e, (name, e)
         assert e["unit"] == "bits/s" and e["value"] > 1e4 and e["identical_to_stock"] is True
         assert e["config"]["streams"] == (64 if name == "e2e_S64" else 1) and e["cpu_baseline"]["value"] > 1e4
-    assert d["also"]["e2e_train"]["config"]["evaluations"] >= 40
+    assert d["also"]["e2e_train"]["config"]["evaluations"] == 14   # (30 training bytes: every even position)
     for name, e in [("headline", d)] + [(k, d["also"][k]) for k in sorted(kernels)]:
         assert "error" not in e, (name, e)
         ro = e["roofline"]
