@@ -39,8 +39,9 @@ def test_bench_line_carries_the_contract(gpu):
     for name in whole:
         e = d["also"][name]
         assert "error" not in e, (name, e)
-        assert e["unit"] == "bits/s" and e["value"] > 1e4 and e["identical_to_stock"] is True
-        assert e["config"]["streams"] == (64 if name == "e2e_S64" else 1) and e["cpu_baseline"]["value"] > 1e4
+        floor = 1e2 if name == "e2e_train" else 1e4   # (a 30-byte training run is fifteen Predictor constructions)
+        assert e["unit"] == "bits/s" and e["value"] > floor and e["identical_to_stock"] is True
+        assert e["config"]["streams"] == (64 if name == "e2e_S64" else 1) and e["cpu_baseline"]["value"] > floor
     assert d["also"]["e2e_train"]["config"]["evaluations"] == 14   # (30 training bytes: every even position)
     for name, e in [("headline", d)] + [(k, d["also"][k]) for k in sorted(kernels)]:
         assert "error" not in e, (name, e)
