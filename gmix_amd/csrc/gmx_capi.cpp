@@ -86,16 +86,18 @@ struct GmxXfer {
   hipEvent_t ev_up = nullptr;    // behind the newest upload
   hipEvent_t ev_dev = nullptr;   // behind the newest device-side use, on the bank's stream
   hipEvent_t ev_down = nullptr;  // behind the newest download
-  bool up_rec = false, dev_rec = false, down_rec = false;
+  hipEvent_t ev_wr = nullptr;    // behind the newest write by ANOTHER bank's kernel, on that bank's stream
+  bool up_rec = false, dev_rec = false, down_rec = false, wr_rec = false;
 };
 static int xfer_init(GmxXfer& x) {
   HIPCHK(hipEventCreateWithFlags(&x.ev_up, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&x.ev_dev, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&x.ev_down, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&x.ev_wr, hipEventDisableTiming));
   return GMX_OK;
 }
 static void xfer_free(GmxXfer& x) {
-  hipEvent_t evs[] = {x.ev_up, x.ev_dev, x.ev_down};
+  hipEvent_t evs[] = {x.ev_up, x.ev_dev, x.ev_down, x.ev_wr};
   for (hipEvent_t e : evs)
     if (e) (void)hipEventDestroy(e);
   x = GmxXfer();
@@ -112,6 +114,18 @@ static int xfer_note_device_use(GmxXfer& x, hipStream_t main) {
 static int xfer_writer_waits(GmxXfer& x, hipStream_t writer) {
   if (x.up_rec) HIPCHK(hipStreamWaitEvent(writer, x.ev_up, 0));
   if (x.dev_rec) HIPCHK(hipStreamWaitEvent(writer, x.ev_dev, 0));
+  if (x.wr_rec) HIPCHK(hipStreamWaitEvent(writer, x.ev_wr, 0));  // (the writer before it: the LSTM's scatter before `into`)
+  return GMX_OK;
+}
+// ... and when its kernel is queued: the batch's own stream waits for it, and so does whoever writes the batch next
+// (another such writer, the next upload).  The mark is an event on the WRITER's stream: recorded on the batch's own
+// stream it would stand behind that stream's running kernel -- the mixers of the chunk before -- and the next writer
+// (the Indirect models of chunk k+1) waited for the mixers of chunk k with nothing to wait for (seen in the kernel
+// timeline: the chain's period was mixers + Indirect models, 5.6 ms, instead of the longest stage's 4.8).
+static int xfer_writer_done(GmxXfer& x, hipStream_t writer, hipStream_t main) {
+  HIPCHK(hipEventRecord(x.ev_wr, writer));
+  x.wr_rec = true;
+  HIPCHK(hipStreamWaitEvent(main, x.ev_wr, 0));
   return GMX_OK;
 }
 // Hardware queues.  The runtime maps a process's streams onto FOUR hardware queues per priority level, round robin,
@@ -145,6 +159,7 @@ static int xfer_begin_upload(GmxXfer& x, hipStream_t main, hipStream_t* own, siz
   if (!*own) HIPCHK(sibling_stream_create(own, main));
   *use = *own;
   if (x.dev_rec) HIPCHK(hipStreamWaitEvent(*use, x.ev_dev, 0));
+  if (x.wr_rec) HIPCHK(hipStreamWaitEvent(*use, x.ev_wr, 0));
   return GMX_OK;
 }
 static int xfer_end_upload(GmxXfer& x, hipStream_t main, hipStream_t use) {
@@ -1730,7 +1745,16 @@ extern "C" int gmx_lstm_set_cu_mask(gmx_lstm* l, const uint32_t* mask, int n_wor
   if (!l || n_words < 0 || (n_words > 0 && !mask)) return GMX_ERR_INVALID;
   HIPCHK(hipSetDevice(l->device));
   LSTM_CLOSE_SESSIONS(l);
-  return stream_with_cu_mask(&l->stream, mask, n_words);
+  int rc = stream_with_cu_mask(&l->stream, mask, n_words);
+  if (rc) return rc;
+  int n = 0;
+  if (n_words > 0) {
+    for (int w = 0; w < n_words; ++w) n += __builtin_popcount(mask[w]);
+  } else {
+    HIPCHK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, l->device));
+  }
+  l->cus = n;  // (which build of the kernel a launch takes: one workgroup per unit or two, gmx_lstm.hip)
+  return GMX_OK;
 }
 
 // Wall-clock cost of n lock-step steps (Predict for all streams, the probabilities on the host, Learn

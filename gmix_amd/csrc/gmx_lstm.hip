@@ -779,15 +779,21 @@ extern "C" int gmx_lstm_prof_read(unsigned long long* out) {
 }
 #endif
 
-extern "C" hipError_t gmx_launch_lstm_kernel(const GmxLstmDev* dv, const GmxLstmRunArgs* args, int n_streams,
+// cus: compute units the launch may use.  With at most one workgroup per unit the build that allows itself 512
+// registers goes: all 77 weight quads of a gate chain in flight at once instead of two stretches of 39 (ONE stream:
+// 21.9 us per byte instead of 24.7; 256 streams: 32.0 instead of 34.8, scripts/lstm_phase_profile.py).
+extern "C" hipError_t gmx_launch_lstm_kernel(const GmxLstmDev* dv, const GmxLstmRunArgs* args, int n_streams, int cus,
                                              hipStream_t stream) {
   (void)hipGetLastError();
-  int build = 2;
-  if (const char* e = getenv("GMX_LSTM_BUILD")) {  // tuning: force the 2- or 3-workgroups-per-CU build
+  int build = (cus > 0 && n_streams <= cus) ? 1 : 2;
+  if (const char* e = getenv("GMX_LSTM_BUILD")) {  // tuning: force the 1-, 2- or 3-workgroups-per-CU build
+    if (e[0] == '1') build = 1;
     if (e[0] == '2') build = 2;
     if (e[0] == '3') build = 3;
   }
-  if (build == 2)
+  if (build == 1)
+    hipLaunchKernelGGL((gmx_lstm_kernel<308, 1, false>), dim3(n_streams), dim3(256), 0, stream, dv, *args);
+  else if (build == 2)
     hipLaunchKernelGGL((gmx_lstm_kernel<154, 2, false>), dim3(n_streams), dim3(256), 0, stream, dv, *args);
   else
     hipLaunchKernelGGL((gmx_lstm_kernel<GMX_LSTM_STRETCH, GMX_LSTM_BLOCKS, false>), dim3(n_streams), dim3(256), 0, stream,
