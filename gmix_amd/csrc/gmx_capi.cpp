@@ -162,6 +162,13 @@ static int xfer_begin_upload(GmxXfer& x, hipStream_t main, hipStream_t* own, siz
   if (x.wr_rec) HIPCHK(hipStreamWaitEvent(*use, x.ev_wr, 0));
   return GMX_OK;
 }
+// The two transfer streams of a bank, made when its first batch is (creating a stream takes milliseconds: not in the
+// first upload of a run).
+static int xfer_streams_ready(hipStream_t main, hipStream_t* up, hipStream_t* down) {
+  if (!*up) HIPCHK(sibling_stream_create(up, main));
+  if (!*down) HIPCHK(sibling_stream_create(down, main));
+  return GMX_OK;
+}
 static int xfer_end_upload(GmxXfer& x, hipStream_t main, hipStream_t use) {
   HIPCHK(hipEventRecord(x.ev_up, use));
   x.up_rec = true;
@@ -1001,7 +1008,9 @@ extern "C" int gmx_batch_create(gmx_batch** out, gmx_group* g, uint64_t max_bits
     const GmxKernelKind kind = kernel_for(g, GMX_MODE_PREDICT | GMX_MODE_LEARN);
     if (kind == GMX_K_SINGLE || kind == GMX_K_WIDE) return GMX_ERR_INVALID;
   }
-  return batch_alloc(out, g, g->S, max_bits, flags);
+  int rc = batch_alloc(out, g, g->S, max_bits, flags);
+  if (rc) return rc;
+  return xfer_streams_ready(g->stream, &g->up_stream, &g->down_stream);
 }
 
 extern "C" void gmx_batch_destroy(gmx_batch* b) { batch_free(b); }

@@ -415,7 +415,11 @@ class MixerPool {
   if (rc == GMX_OK) {                                                                                    \
     const auto step_t0 = std::chrono::steady_clock::now();                                               \
     if ((rc = (call))) what = #call;                                                                     \
-    if (trace_) step_seconds_[#call] += std::chrono::duration<double>(std::chrono::steady_clock::now() - step_t0).count(); \
+    if (trace_) {                                                                                        \
+      const double step_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - step_t0).count(); \
+      step_seconds_[#call] += step_s;                                                                    \
+      if (round_ < 2) fprintf(stderr, "[gmx pool] round %llu: %8.3f ms  %.40s\n", (unsigned long long)round_, step_s * 1e3, #call); \
+    }                                                                                                    \
   }
     if (maxn > 0) {
       if (parts_ & kLstm) {
