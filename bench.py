@@ -333,6 +333,7 @@ def main():
                     help="--config stock*: the lane-pair kernel (gmx_wide.hip) instead of the generated streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="only the headline workload")
+    ap.add_argument("--only-also", default="", help="comma-separated: of the also{} entries, only these")
     ap.add_argument("--e2e-bytes", type=int, default=30000, help="bytes per file of the also.e2e_* entries")
     ap.add_argument("--train-bytes", type=int, default=20000, help="also.e2e_train: training file (a test run shrinks it)")
     ap.add_argument("--test-bytes", type=int, default=4000, help="also.e2e_train: test file")
@@ -398,9 +399,10 @@ def main():
                         stock_pairs=args.stock_pairs, variant=args.variant, want_cpu=not args.no_cpu_baseline,
                         cpu_sample_bits=args.cpu_sample_bits)
     also = {}
+    only = {x for x in args.only_also.split(",") if x}
     if not args.no_also:
         for name in ALSO:
-            if name == args.config:
+            if name == args.config or (only and name not in only):
                 continue
             try:
                 # two warm-up launches: each of the library's two decay-table slots is allocated before the clock runs
@@ -415,7 +417,7 @@ def main():
         if rank == 0 and "cpu_baseline" in also.get("stock_held", {}) and "error" not in also.get("stock_S1", {"error": 1}):
             # one stream of the same workload: the one-core reference figure is the same measurement
             also["stock_S1"]["cpu_baseline"] = dict(also["stock_held"]["cpu_baseline"])
-        if world == 1:
+        if dist is None:
             # the producers in front of the mixers, timed by their own scripts' code:
             # the 41 Indirect models (bits/s) and the LSTM byte model (bytes/s), each with roofline + cpu_baseline
             # ... and whole files end to end: the reference's feature models and coder on the host running ahead of
@@ -426,6 +428,8 @@ def main():
                                      ("e2e_S1_mixers", "bench_e2e.py", {"streams": 1, "variant": "mixers"}),
                                      ("e2e_S64", "bench_e2e.py", {"streams": 64, "variant": "chain"}),
                                      ("e2e_train", "bench_e2e.py", {"training": True})):
+                if only and name not in only:
+                    continue
                 try:
                     mod = aux_bench(script)
                     if kw.get("training"):
@@ -443,6 +447,27 @@ def main():
                                               c.get("bytes_per_stream_per_step")), 0, rf.get("build")))
                 except Exception as e:
                     also[name] = {"error": f"{type(e).__name__}: {e}"}
+        elif not only or "e2e_S64" in only:
+            # whole files on every GPU at once (weak scaling: 64 files per GPU, a process per GPU, no exchange): every
+            # rank compresses its own 64 files on its own device; a rank that fails reports -1 and still takes part in
+            # the three collectives below
+            mine = {"value": -1.0, "seconds": -1.0, "bits": 0.0}
+            try:
+                r = aux_bench("bench_e2e.py").measure(streams=64, n_bytes=args.e2e_bytes, variant="chain",
+                                                      device=local_rank, verify=(rank == 0), cpu=False)
+                mine = {"value": r["value"], "seconds": r["seconds"], "bits": 8.0 * 64 * args.e2e_bytes}
+            except Exception as e:
+                r = {"error": f"{type(e).__name__}: {e}"}
+            comm.barrier()
+            rates, secs, bits = comm.gather(mine["value"]), comm.gather(mine["seconds"]), comm.gather(mine["bits"])
+            if rank == 0:
+                ok = all(v > 0 for v in rates)
+                e = dict(r)
+                e.update({"n_gpus": world, "per_rank": {"bits_per_s": rates, "seconds": secs},
+                          "value": (sum(bits) / max(secs)) if ok else None, "scaling": "weak"})
+                if not ok:
+                    e["error"] = "a rank failed: " + str(rates)
+                also["e2e_S64"] = e
     if rank == 0:
         out = {"metric": "mixer bits/sec (synthetic 256-input mixer streams, forward+update)",
                "value": head["value"], "unit": "bits/s", "n_gpus": world, "steps": head["steps"],

@@ -61,6 +61,7 @@ struct BatchedOptions {
   uint64_t chunk_bits = 2048;  // bits per stream and launch (a multiple of 8: chunks end on byte boundaries)
   bool analysis = true;        // runner-utils.cpp:47
   bool progress = true;        // runner-utils.cpp:59-63
+  int device = -1;             // BatchedCompressFiles: the pool's device (-1: $GMX_DEVICE, else 0) -- one process per GPU
   bool pin_threads = true;     // BatchedCompressFiles: threads onto the cores of the device's NUMA node
   int max_cpus = -1;           // ... onto at most this many of them.  -1: twice what the container's CPU quota is worth
                                // (threads spread over every core of the node spend the quota in a burst and are then
@@ -534,7 +535,7 @@ inline int BatchedCompressFiles(std::vector<BatchedJob>& jobs, const BatchedOpti
   opt.progress = false;
   const int S = (int)jobs.size();
   if (S == 0) return 0;
-  MixerPool pool(S);
+  MixerPool pool(S, opt.device);
   pool.Install();
   std::mutex construct;  // Predictor::Predictor draws the LSTM's weights from rand() after srand() (predictor.cpp:18)
   std::mutex start_mu;

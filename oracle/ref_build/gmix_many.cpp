@@ -3,7 +3,7 @@
 // Linked by oracle/ref_build/Makefile against the reference's own translation units (feature models, coder,
 // runner-utils) with Predictor::AddMixers constructing gmx::GpuMixer -- the reference calls the product.
 //
-// usage: gmix_many [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] <out dir> <input file>...
+// usage: gmix_many [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--device d] <out dir> <input file>...
 //   each input is compressed to <out dir>/<index>.gmix exactly as `gmix -c` would (runner-utils.cpp:88-121);
 //   -n limits every input to its first n bytes (written to <out dir>/<index>.in first).
 //   One JSON line on stdout: per-file sizes and times, the wall time of the compression phase, bits, launches.
@@ -30,11 +30,13 @@ int main(int argc, char** argv) {
       opt.pin_threads = false;
     else if (!strcmp(argv[a], "--cpus") && a + 1 < argc)
       opt.max_cpus = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--device") && a + 1 < argc)
+      opt.device = atoi(argv[++a]);
     else
       break;
   }
   if (argc - a < 2) {
-    fprintf(stderr, "usage: %s [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] <out dir> <input file>...\n", argv[0]);
+    fprintf(stderr, "usage: %s [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--device d] <out dir> <input file>...\n", argv[0]);
     return 2;
   }
   const std::string out_dir = argv[a++];

@@ -59,7 +59,7 @@ def cpu_quota():
         return None
 
 
-def measure(streams=1, n_bytes=30000, variant="chain", chunk=2048, verify=True, cpu=True):
+def measure(streams=1, n_bytes=30000, variant="chain", chunk=2048, verify=True, cpu=True, device=None):
     exe = os.path.join(REF, EXE[variant])
     if not os.path.exists(exe):
         raise RuntimeError(f"{exe} missing (make -C oracle/ref_build batched, needs /root/reference)")
@@ -71,8 +71,8 @@ def measure(streams=1, n_bytes=30000, variant="chain", chunk=2048, verify=True, 
             f = os.path.join(tmp, f"f{k}")
             open(f, "wb").write(data)
             files.append(f)
-        r = subprocess.run([exe, "-T", str(chunk), os.path.join(tmp, "out")] + files, capture_output=True, text=True,
-                           timeout=1500)
+        r = subprocess.run([exe, "-T", str(chunk)] + (["--device", str(device)] if device is not None else []) +
+                           [os.path.join(tmp, "out")] + files, capture_output=True, text=True, timeout=1500)
         if r.returncode != 0:
             raise RuntimeError(f"{EXE[variant]} failed: {r.stderr[-500:]}")
         st = json.loads(r.stdout.strip().splitlines()[-1])

@@ -69,3 +69,21 @@ def test_bench_multi_rank_path_over_rccl(gpu):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == n and line["config"]["bits_per_step"] == 256 * 128 * n
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+def test_bench_whole_files_on_every_rank(gpu):
+    """bench.py across ranks also compresses whole files on every GPU (64 files per rank on the rank's own device, a
+    process per GPU, nothing exchanged but the figures): also.e2e_S64 carries every rank's rate and the aggregate."""
+    n = _n_gpus()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GMX_BENCH_FORCE_DIST="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--streams", "256", "--bits", "128",
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--only-also", "e2e_S64", "--e2e-bytes", "6000"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    e = line["also"]["e2e_S64"]
+    assert "error" not in e, e
+    assert e["n_gpus"] == n and len(e["per_rank"]["bits_per_s"]) == n and min(e["per_rank"]["bits_per_s"]) > 1e5
+    assert e["identical_to_stock"] is True and e["value"] > 1e5
