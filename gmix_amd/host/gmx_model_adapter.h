@@ -86,7 +86,7 @@ inline bool ChainFused() {
 // the device-side models' Predict then only RECORDS its inputs and Learn the coded bit, straight into the pinned
 // arrays of the banks' batches -- the mixers {predictions, active_models, 33 contexts, bit}, the Indirect models
 // {41 contexts, bit_context, bit}, the LSTM {PPM byte distribution, byte} -- a full chunk is uploaded and run
-// behind the chunk before it (two sets of batches used alternately) and its
+// behind the chunk before it (a ring of three sets of batches, MixerPool::kRing) and its
 // probabilities come back one chunk later, in order, to whoever consumes them (the arithmetic coder:
 // gmx_batched.h).
 // ------------------------------------------------------------------------------------------------

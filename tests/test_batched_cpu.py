@@ -2,7 +2,7 @@
 MixerPool of gmx_model_adapter.h): the reference's CLI, tester and a many-file driver built on it, the C-ABI calls
 answered by the oracle (tests/cpp/gmx_abi_oracle_shim.c -- test-only; the product has no CPU path), beside the
 stock build.  What is checked here: records written at the right bit, chunks handed in and drained in order
-through the two-batch ring, ragged ends, the coder fed in order, the analysis rows, thread hand-offs.  The
+through the ring of batches, ragged ends, the coder fed in order, the analysis rows, thread hand-offs.  The
 same comparisons against libgmxmix.so on an MI355X: tests/test_gpu_batched.py."""
 import os
 
