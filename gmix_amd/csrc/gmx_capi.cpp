@@ -88,6 +88,7 @@ struct GmxXfer {
   hipEvent_t ev_down = nullptr;  // behind the newest download
   hipEvent_t ev_wr = nullptr;    // behind the newest write by ANOTHER bank's kernel, on that bank's stream
   bool up_rec = false, dev_rec = false, down_rec = false, wr_rec = false;
+  bool idle = false;             // the host has waited for everything recorded above and nothing was queued since
 };
 static int xfer_init(GmxXfer& x) {
   HIPCHK(hipEventCreateWithFlags(&x.ev_up, hipEventDisableTiming));
@@ -105,6 +106,7 @@ static void xfer_free(GmxXfer& x) {
 static int xfer_note_device_use(GmxXfer& x, hipStream_t main) {
   HIPCHK(hipEventRecord(x.ev_dev, main));
   x.dev_rec = true;
+  x.idle = false;
   return GMX_OK;
 }
 // A writer on ANOTHER bank's stream (the LSTM's scatter, the Indirect models' `into`) is about to write this batch's
@@ -125,6 +127,7 @@ static int xfer_writer_waits(GmxXfer& x, hipStream_t writer) {
 static int xfer_writer_done(GmxXfer& x, hipStream_t writer, hipStream_t main) {
   HIPCHK(hipEventRecord(x.ev_wr, writer));
   x.wr_rec = true;
+  x.idle = false;
   HIPCHK(hipStreamWaitEvent(main, x.ev_wr, 0));
   return GMX_OK;
 }
@@ -172,10 +175,23 @@ static int xfer_streams_ready(hipStream_t main, hipStream_t* up, hipStream_t* do
 static int xfer_end_upload(GmxXfer& x, hipStream_t main, hipStream_t use) {
   HIPCHK(hipEventRecord(x.ev_up, use));
   x.up_rec = true;
+  x.idle = false;
   if (use != main) HIPCHK(hipStreamWaitEvent(main, x.ev_up, 0));
   return GMX_OK;
 }
 static int xfer_begin_download(GmxXfer& x, hipStream_t main, hipStream_t* own, size_t bytes, hipStream_t* use) {
+  if (x.idle) {
+    // The host has already waited for the batch's work (gmx_batch_wait) and queued nothing on it since: the copy
+    // depends on nothing and runs at once on the download stream -- NOT behind whatever else the bank's stream holds
+    // by now.  This is how a pipelined caller should fetch results: a download queued right behind its kernel is a
+    // copy that waits for milliseconds, and the copy engines take copies in order -- the uploads of the NEXT chunks
+    // queued behind it waited with it (seen in the chain's timeline with 16 files: every chunk's upload ran only
+    // when the mixers of the chunk before had finished, and the LSTM's scatter and both long kernels behind it: 6.4 ms
+    // per chunk instead of 5.0).
+    if (!*own) HIPCHK(sibling_stream_create(own, main));
+    *use = *own;
+    return GMX_OK;
+  }
   if (bytes < kBatchOwnStreamMin) {
     *use = main;
     return GMX_OK;
@@ -190,6 +206,7 @@ static int xfer_begin_download(GmxXfer& x, hipStream_t main, hipStream_t* own, s
 static int xfer_end_download(GmxXfer& x, hipStream_t use) {
   HIPCHK(hipEventRecord(x.ev_down, use));
   x.down_rec = true;
+  x.idle = false;
   return GMX_OK;
 }
 // before a kernel overwrites the batch's result arrays
@@ -199,24 +216,30 @@ static int xfer_before_run(GmxXfer& x, hipStream_t main) {
 }
 static int xfer_wait(GmxXfer& x) {
   if (x.up_rec) HIPCHK(hipEventSynchronize(x.ev_up));
+  if (x.wr_rec) HIPCHK(hipEventSynchronize(x.ev_wr));
   if (x.dev_rec) HIPCHK(hipEventSynchronize(x.ev_dev));
   if (x.down_rec) HIPCHK(hipEventSynchronize(x.ev_down));
+  x.idle = true;
   return GMX_OK;
 }
 
 
-// Per-stream counts of a launch over streams of different lengths (GmxRunArgs::T_list and its cousins): two
-// staging slots used alternately, a slot reused only when the launch that read it is done.
+// Per-stream counts of a launch over streams of different lengths (GmxRunArgs::T_list and its cousins): staging
+// slots used in turn, a slot reused only when the launch that read it is done.
+// Staging slots of what a launch reads beside its batch (the per-stream counts of a ragged launch, the mixers' decay
+// tables): as many as launches may be queued before the host has to wait for one to finish -- a caller that keeps a ring
+// of kStageSlots batches in flight (gmx::MixerPool::kRing) never waits here.
+static constexpr int kStageSlots = 4;
 struct GmxCountList {
-  uint64_t* dev[2] = {nullptr, nullptr};
-  uint64_t* host[2] = {nullptr, nullptr};  // pinned
-  hipEvent_t done[2] = {nullptr, nullptr};
-  bool busy[2] = {false, false};
+  uint64_t* dev[kStageSlots] = {};
+  uint64_t* host[kStageSlots] = {};  // pinned
+  hipEvent_t done[kStageSlots] = {};
+  bool busy[kStageSlots] = {};
   size_t cap = 0;
   unsigned seq = 0;
 };
 static void count_list_free(GmxCountList& c) {
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < kStageSlots; ++k) {
     if (c.dev[k]) (void)hipFree(c.dev[k]);
     if (c.host[k]) (void)hipHostFree(c.host[k]);
     if (c.done[k]) (void)hipEventDestroy(c.done[k]);
@@ -225,13 +248,13 @@ static void count_list_free(GmxCountList& c) {
 }
 // counts [n] -> device, queued on `st` in front of the kernel that reads them; *dev_out is that kernel's argument
 static int count_list_stage(GmxCountList& c, const uint64_t* counts, int n, hipStream_t st, const uint64_t** dev_out) {
-  const int k = (int)(c.seq++ & 1u);
+  const int k = (int)(c.seq++ % (unsigned)kStageSlots);
   if (c.busy[k]) {
     HIPCHK(hipEventSynchronize(c.done[k]));
     c.busy[k] = false;
   }
   if ((size_t)n > c.cap) {
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < kStageSlots; ++j) {
       if (c.busy[j]) {
         HIPCHK(hipEventSynchronize(c.done[j]));
         c.busy[j] = false;
@@ -243,7 +266,7 @@ static int count_list_stage(GmxCountList& c, const uint64_t* counts, int n, hipS
     }
     c.cap = 0;
     const size_t cap = (size_t)n + 64;
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < kStageSlots; ++j) {
       HIPCHK(hipMalloc((void**)&c.dev[j], cap * sizeof(uint64_t)));
       HIPCHK(hipHostMalloc((void**)&c.host[j], cap * sizeof(uint64_t), hipHostMallocDefault));
       if (!c.done[j]) HIPCHK(hipEventCreateWithFlags(&c.done[j], hipEventDisableTiming));
@@ -257,7 +280,7 @@ static int count_list_stage(GmxCountList& c, const uint64_t* counts, int n, hipS
 }
 // ... and behind that kernel
 static int count_list_used(GmxCountList& c, hipStream_t st) {
-  const int k = (int)((c.seq - 1u) & 1u);
+  const int k = (int)((c.seq - 1u) % (unsigned)kStageSlots);
   HIPCHK(hipEventRecord(c.done[k], st));
   c.busy[k] = true;
   return GMX_OK;
@@ -275,7 +298,7 @@ struct gmx_group {
   unsigned lds_bytes = 0;
   std::vector<uint64_t> steps;     // host mirror of Mixer::steps_ (identical for all mixers of a stream)
   std::vector<uint8_t> fwd_done;   // per-bit protocol: forward seen, learn allowed
-  // decay tables: two staging slots used alternately, so the host prepares launch k+1 while
+  // decay tables: staging slots used in turn, so the host prepares the launches ahead while
   // launch k still reads its tables
   struct DecaySlot {
     float* dev = nullptr;
@@ -294,7 +317,7 @@ struct gmx_group {
     uint32_t* amb_host = nullptr;  // pinned
     float* patch_host = nullptr;   // pinned [kDecayAmbCap]
     size_t st_cap = 0;
-  } decay[2];
+  } decay[kStageSlots];
   GmxCountList counts;                // per-stream bit counts of ragged launches
   hipStream_t copy_stream = nullptr;  // uploads of the decay tables, beside the running kernel
   // record batches travel on streams of their own, beside the running kernel (BASELINE configs[3]:
@@ -782,39 +805,48 @@ static int prepare_decay(gmx_group* g, int s0, int ns, uint64_t T, int learn, gm
     if (it == uniq.end()) it = uniq.emplace(st, (uint32_t)uniq.size()).first;
     idx[i] = it->second;
   }
-  gmx_group::DecaySlot& d = g->decay[g->run_seq++ & 1u];
+  gmx_group::DecaySlot& d = g->decay[g->run_seq++ % (unsigned)kStageSlots];
   *out = &d;
-  // the launch before last read this slot: it must be done before the staging is rewritten
+  // the launch kStageSlots back read this slot: it must be done before the staging is rewritten
   if (d.busy) {
     HIPCHK(hipEventSynchronize(d.done));
     d.busy = false;
   }
+  // (what one slot lacks, every slot gets now: allocations belong to a run's first launch, not to its first four)
   const size_t need = (size_t)uniq.size() * T;
-  if (need > d.cap) {
-    if (d.dev) (void)hipFree(d.dev);
-    if (d.host) (void)hipHostFree(d.host);
-    d.dev = nullptr;
-    d.host = nullptr;
-    d.cap = 0;
-    size_t cap = need + need / 2 + 1024;
-    HIPCHK(hipMalloc((void**)&d.dev, cap * sizeof(float)));
-    HIPCHK(hipHostMalloc((void**)&d.host, cap * sizeof(float), hipHostMallocDefault));
-    d.cap = cap;
-  }
-  if ((size_t)ns > d.idx_cap) {  // one row index per stream of the launch
-    if (d.idx_dev) (void)hipFree(d.idx_dev);
-    if (d.idx_host) (void)hipHostFree(d.idx_host);
-    d.idx_dev = nullptr;
-    d.idx_host = nullptr;
-    d.idx_cap = 0;
-    const size_t icap = (size_t)ns + 64;
-    HIPCHK(hipMalloc((void**)&d.idx_dev, icap * sizeof(uint32_t)));
-    HIPCHK(hipHostMalloc((void**)&d.idx_host, icap * sizeof(uint32_t), hipHostMallocDefault));
-    d.idx_cap = icap;
-  }
-  if (!d.done) {
-    HIPCHK(hipEventCreateWithFlags(&d.done, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&d.ready, hipEventDisableTiming));
+  if (need > d.cap || (size_t)ns > d.idx_cap || !d.done) {
+    for (gmx_group::DecaySlot& e : g->decay) {
+      if (e.busy) {
+        HIPCHK(hipEventSynchronize(e.done));
+        e.busy = false;
+      }
+      if (need > e.cap) {
+        if (e.dev) (void)hipFree(e.dev);
+        if (e.host) (void)hipHostFree(e.host);
+        e.dev = nullptr;
+        e.host = nullptr;
+        e.cap = 0;
+        size_t cap = need + need / 2 + 1024;
+        HIPCHK(hipMalloc((void**)&e.dev, cap * sizeof(float)));
+        HIPCHK(hipHostMalloc((void**)&e.host, cap * sizeof(float), hipHostMallocDefault));
+        e.cap = cap;
+      }
+      if ((size_t)ns > e.idx_cap) {  // one row index per stream of the launch
+        if (e.idx_dev) (void)hipFree(e.idx_dev);
+        if (e.idx_host) (void)hipHostFree(e.idx_host);
+        e.idx_dev = nullptr;
+        e.idx_host = nullptr;
+        e.idx_cap = 0;
+        const size_t icap = (size_t)ns + 64;
+        HIPCHK(hipMalloc((void**)&e.idx_dev, icap * sizeof(uint32_t)));
+        HIPCHK(hipHostMalloc((void**)&e.idx_host, icap * sizeof(uint32_t), hipHostMallocDefault));
+        e.idx_cap = icap;
+      }
+      if (!e.done) {
+        HIPCHK(hipEventCreateWithFlags(&e.done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e.ready, hipEventDisableTiming));
+      }
+    }
   }
   if (!g->copy_stream) HIPCHK(sibling_stream_create(&g->copy_stream, g->stream));
   // Streams at the same bit count share a row; with many different counts the device makes the

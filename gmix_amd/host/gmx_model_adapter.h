@@ -421,6 +421,25 @@ class MixerPool {
       if (round_ < 2) fprintf(stderr, "[gmx pool] round %llu: %8.3f ms  %.40s\n", (unsigned long long)round_, step_s * 1e3, #call); \
     }                                                                                                    \
   }
+    // The oldest chunk in flight first: wait for its kernels (the mixers' are the last of the chain) and queue its
+    // downloads -- of batches nothing else is queued on, so they run at once on the banks' download streams -- BEFORE
+    // this chunk's uploads, which are tens of megabytes with many streams and would be in front of them in the copy
+    // engines' queues.  They are waited for at the end of this call.
+    const int other = (c + 1) % kRing;  // its arrays are the ones the streams fill next
+    if (busy_[other]) {
+      const uint64_t on = maxn_[other];
+      GMX_POOL_STEP(gmx_batch_wait(ring_[other]));
+      GMX_POOL_STEP(gmx_batch_download(ring_[other], on));
+      if (models_back_ && (parts_ & kIndirect)) {
+        GMX_POOL_STEP(gmx_ind_batch_wait(iring_[other]));
+        GMX_POOL_STEP(gmx_ind_batch_download(iring_[other], on));
+      }
+      if (parts_ & kLstm) {
+        GMX_POOL_STEP(gmx_lstm_batch_wait(lring_[other]));
+        GMX_POOL_STEP(gmx_lstm_batch_download(lring_[other], on / 8));  // (44 bytes per byte: the context at least is wanted)
+      }
+    }
+    const auto lead_tw = std::chrono::steady_clock::now();
     if (maxn > 0) {
       if (parts_ & kLstm) {
         // LstmModel::Predict x 8 / Learn for every byte of the chunk, then its prediction into the mixers' records
@@ -433,33 +452,32 @@ class MixerPool {
       if (parts_ & kLstm) {
         GMX_POOL_STEP(gmx_lstm_feed(lstm_, lring_[c], maxn / 8, ring_[c], lstm_slot_, mixer_ctx_col_,
                                     (parts_ & kIndirect) && ind_ctx_col_ >= 0 ? iring_[c] : nullptr, ind_ctx_col_));
-        GMX_POOL_STEP(gmx_lstm_batch_download(lring_[c], maxn / 8));  // (44 bytes per byte: the context at least is wanted)
       }
       if (parts_ & kIndirect) {
         GMX_POOL_STEP(gmx_indirect_run_ragged(ind_, iring_[c], n_cur_.data(), 1, ring_[c]));
-        if (models_back_) GMX_POOL_STEP(gmx_ind_batch_download(iring_[c], maxn));
       }
       GMX_POOL_STEP(gmx_group_run_ragged(group_, ring_[c], n_cur_.data(), 1));
-      GMX_POOL_STEP(gmx_batch_download(ring_[c], maxn));
+      // (no download queued here: a copy that waits milliseconds for its kernel holds up the uploads of the chunks
+      // behind it in the copy engines' queues -- the results are fetched below, when their kernels are done)
       if (rc == GMX_OK) {
         busy_[c] = true;
         bits_submitted_ += sum;
       }
     }
     n_in_[c] = n_cur_;
+    maxn_[c] = maxn;
     std::fill(n_cur_.begin(), n_cur_.end(), 0);
-    const int other = (c + 1) % kRing;  // the oldest chunk in flight: its arrays are the ones to fill next
     const auto lead_t1 = std::chrono::steady_clock::now();
     if (rc == GMX_OK && busy_[other]) {
       busy_[other] = false;
-      GMX_POOL_STEP(gmx_batch_wait(ring_[other]));
+      GMX_POOL_STEP(gmx_batch_wait(ring_[other]));  // (the downloads queued at the top of this call)
       if (models_back_ && (parts_ & kIndirect)) GMX_POOL_STEP(gmx_ind_batch_wait(iring_[other]));
       if (parts_ & kLstm) GMX_POOL_STEP(gmx_lstm_batch_wait(lring_[other]));
     }
 #undef GMX_POOL_STEP
     if (rc) Fail(what, rc);
-    submit_seconds_ += std::chrono::duration<double>(lead_t1 - lead_t0).count();
-    wait_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - lead_t1).count();
+    submit_seconds_ += std::chrono::duration<double>(lead_t1 - lead_tw).count();
+    wait_seconds_ += std::chrono::duration<double>((lead_tw - lead_t0) + (std::chrono::steady_clock::now() - lead_t1)).count();
     cur_ = other;
     arrived_ = 0;
     ++round_;
@@ -473,6 +491,13 @@ class MixerPool {
     if ((parts_ & kLstm) && (n & 7)) return GMX_ERR_STATE;  // the LSTM's records are bytes
     n_cur_[slot] = n;
     const uint64_t my_round = round_;
+    if (trace_) {  // GMX_POOL_TRACE: a stream that took unusually long over its chunk (every other stream waits for it)
+      const auto now = std::chrono::steady_clock::now();
+      if (left_at_.size() == (size_t)S_ && my_round > 3) {
+        const double ms = std::chrono::duration<double>(now - left_at_[slot]).count() * 1e3;
+        if (ms > 5.0) fprintf(stderr, "[gmx pool] round %llu: stream %d filled its chunk in %.1f ms\n", (unsigned long long)my_round, slot, ms);
+      }
+    }
     if (++arrived_ >= participants_)
       Lead();
     else
@@ -502,6 +527,10 @@ class MixerPool {
     n_in_[cur_][slot] = 0;
     streams_[slot].t = 0;
     Records(slot);
+    if (trace_) {
+      if (left_at_.size() != (size_t)S_) left_at_.assign(S_, std::chrono::steady_clock::now());
+      left_at_[slot] = std::chrono::steady_clock::now();
+    }
     return GMX_OK;
   }
   void Leave(int slot) {
@@ -530,17 +559,23 @@ class MixerPool {
   // Three sets of batches in turn: the hosts fill one while the device works on the two before it.  With two, the
   // hosts could only start on chunk k+2 when chunk k had come back whole, and the longest stage of the chain (the
   // LSTM) stood still meanwhile: one compressor ran at 4.0 us per bit, with three at the LSTM stage's own 3.4.
-  static constexpr int kRing = 3;
+  // ... and four since the stages of the chain are of equal length (LSTM 4.7-4.9 ms, mixers 4.8-5.0 ms per chunk): with
+  // three the hosts' own turn (wake up, drain, fill 2.3 ms, hand in) sat right on the critical path, and every bit of
+  // jitter in it opened a gap in both stages (16 files: 5.9 ms per chunk against kernels of 5.0).  The library stages
+  // what a launch reads beside its batch in as many slots (kStageSlots, gmx_capi.cpp).
+  static constexpr int kRing = 4;
   gmx_batch* ring_[kRing] = {};
   gmx_ind_batch* iring_[kRing] = {};
   gmx_lstm_batch* lring_[kRing] = {};
   bool busy_[kRing] = {};
+  uint64_t maxn_[kRing] = {};   // bits of the longest stream of the chunk in each ring slot
   int cur_ = 0, parts_ = 0, lstm_slot_ = -1, mixer_ctx_col_ = -1, ind_ctx_col_ = -1;
   bool models_back_ = false, all_outputs_ = false;
   uint64_t T_ = 0, round_ = 0, bits_submitted_ = 0;
   double submit_seconds_ = 0, wait_seconds_ = 0;
   const bool trace_ = getenv("GMX_POOL_TRACE") != nullptr;
   std::map<std::string, double> step_seconds_;
+  std::vector<std::chrono::steady_clock::time_point> left_at_;  // (trace) when each stream last left Arrive
   int n_pad_ = 0, mask_words_ = 0, M_ = 0, K_ = 0;
   int participants_ = 0, arrived_ = 0;
   std::vector<uint64_t> n_cur_, n_in_[kRing], n_bytes_;

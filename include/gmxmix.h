@@ -146,7 +146,12 @@ const float* gmx_batch_last_outputs(gmx_batch* b);  /* [S][M] after gmx_batch_do
  * batch: an upload starts when the last run of THIS batch is done and overlaps whatever runs on
  * other batches (double buffering: run(A); upload(B); run(B); download(A); wait(A); refill A ...);
  * everything queued on the group after gmx_batch_upload returns sees the new records.  A download
- * follows everything queued on the group so far.  wait = this batch's upload, runs and download.
+ * follows everything queued on the group so far -- except for a batch the host has already waited for
+ * (gmx_batch_wait) with nothing queued on it since: that one is fetched at once, whatever the group's stream
+ * holds by then.  A caller with several batches in flight fetches that way -- wait(A); download(A); wait(A) -- when
+ * A's turn comes, rather than queueing download(A) right behind run(A): a copy that waits for its kernel holds up
+ * the copies queued behind it, the uploads of the batches after it among them.  wait = this batch's upload, runs
+ * and download.  (The same holds for gmx_ind_batch_* and gmx_lstm_batch_*.)
  * The batch's host arrays are read (upload) and written (download) when the copies execute, not when
  * the calls return: leave them alone between gmx_batch_upload / gmx_batch_download and the
  * gmx_batch_wait that follows. */

@@ -27,6 +27,14 @@ for k, v in by.items():
     print(f"{k:5s} n={len(v):4d} dur ms avg {sum(d[mid]) / max(1, len(d[mid])):.3f}  gap-to-next ms avg {sum(gaps[mid]) / max(1, len(gaps[mid])):.3f}  period {(v[mid][-1][0] - v[mid][0][0]) / 1e6 / max(1, len(v[mid]) - 1):.3f}")
 ls = [s for s, e in by.get("lstm", [])]
 print("lstm start-to-start ms, in order:", " ".join(f"{(b - a) / 1e6:.1f}" for a, b in zip(ls, ls[1:])))
+if len(ls) > 24:   # the rows around the longest wait between two LSTM launches (past the start-up)
+    k = max(range(12, len(ls) - 2), key=lambda i: ls[i + 1] - ls[i])
+    lo, hi = ls[k] - 8e6, ls[k + 1] + 8e6
+    print(f"around the longest LSTM start-to-start ({(ls[k + 1] - ls[k]) / 1e6:.1f} ms, round {k}): kind start end (all kernels of the trace)")
+    for r in rows:
+        st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if lo <= st - t0 <= hi:
+            print(f"  {r['Kernel_Name'][:44]:44s} {(st - t0) / 1e6:9.3f} {(en - t0) / 1e6:9.3f}  queue {r.get('Queue_Id', '?')} stream {r.get('Stream_Id', '?')} grid {r.get('Grid_Size_X', r.get('Grid_Size', '?'))}")
 print("first rounds (ms since first kernel): kind start end")
 for s, e, k in ev[len(ev) // 2: len(ev) // 2 + 16]: print(f"  {k:5s} {(s - t0) / 1e6:9.3f} {(e - t0) / 1e6:9.3f}")
 PY
