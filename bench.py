@@ -24,7 +24,7 @@ way (barrier, K steps, max over ranks) with its own roofline and one-core refere
   lstm         (one GPU) the LSTM byte model, 1024 streams, bytes/s -- scripts/bench_lstm.py
   e2e_S1 / e2e_S1_mixers / e2e_S64   (one GPU) whole files through the run-ahead compressor: the reference's feature
                models and coder on the host cores, LSTM + Indirect models + mixers (or the mixers alone) on the device in
-               a ring of three batches; 1 file and 64 files side by side -- scripts/bench_e2e.py
+               a ring of four batches; 1 file and 64 files side by side -- scripts/bench_e2e.py
   e2e_train    (one GPU) `gmix -t` (runner_utils::RunTraining) the same way: training Predictor and scored copy
                running ahead -- scripts/bench_e2e.py measure_training()
 (--no-also leaves them out; --config X makes X the headline workload for profiling.)

@@ -9,7 +9,7 @@
 //                              run, the mixers (gmx::GpuMixer in run-ahead mode, gmx_model_adapter.h) only record
 //                              {predictions, active_models, 33 contexts, bit} into the pinned arrays of a gmx_batch
 //     device, bits t-T .. t    gmx_batch_upload / gmx_group_run / gmx_batch_download on the chunk recorded before
-//                              (a ring of three batches, MixerPool::kRing: BASELINE configs[3]'s double-buffered
+//                              (a ring of four batches, MixerPool::kRing: BASELINE configs[3]'s double-buffered
 //                              batches with one more in flight) -- and, when the Predictor's Indirect models and LSTM
 //                              are gmx::GpuIndirect / gmx::GpuLstmModel too, gmx_lstm_run -> gmx_lstm_feed ->
 //                              gmx_indirect_run(into) in front of it, each bank on a stream of its own

@@ -86,7 +86,7 @@ inline bool ChainFused() {
 // the device-side models' Predict then only RECORDS its inputs and Learn the coded bit, straight into the pinned
 // arrays of the banks' batches -- the mixers {predictions, active_models, 33 contexts, bit}, the Indirect models
 // {41 contexts, bit_context, bit}, the LSTM {PPM byte distribution, byte} -- a full chunk is uploaded and run
-// behind the chunk before it (a ring of three sets of batches, MixerPool::kRing) and its
+// behind the chunk before it (a ring of four sets of batches, MixerPool::kRing) and its
 // probabilities come back one chunk later, in order, to whoever consumes them (the arithmetic coder:
 // gmx_batched.h).
 // ------------------------------------------------------------------------------------------------
@@ -556,7 +556,7 @@ class MixerPool {
   std::condition_variable cv_;
   std::atomic<int> status_{0};
   std::string error_;
-  // Three sets of batches in turn: the hosts fill one while the device works on the two before it.  With two, the
+  // Three sets of batches at first: the hosts fill one while the device works on the two before it.  With two, the
   // hosts could only start on chunk k+2 when chunk k had come back whole, and the longest stage of the chain (the
   // LSTM) stood still meanwhile: one compressor ran at 4.0 us per bit, with three at the LSTM stage's own 3.4.
   // ... and four since the stages of the chain are of equal length (LSTM 4.7-4.9 ms, mixers 4.8-5.0 ms per chunk): with

@@ -84,7 +84,7 @@ def measure(streams=1, n_bytes=30000, variant="chain", chunk=2048, verify=True, 
                "value": st["bits_per_second"], "unit": "bits/s", "n_gpus": 1, "higher_is_better": True,
                "dtype": "f32", "data": "real text",
                "config": {"workload": f"{S} file(s) x {n_bytes} bytes of {src}, compressed side by side, "
-                                      f"{chunk}-bit chunks through a ring of three batches", "streams": S,
+                                      f"{chunk}-bit chunks through a ring of four batches", "streams": S,
                           "bytes_per_file": n_bytes, "chunk_bits": chunk, "variant": variant,
                           "host_threads": S, "host_cpu": host_cpu(), "cpus_visible": os.cpu_count(),
                           "cpu_quota_cores": quota, "threads_pinned_to_gpu_numa_node": st["pinned_threads"]},

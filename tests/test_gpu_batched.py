@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("exe", ["gmix_batched", "gmix_chain_batched"])
 def test_batched_compress_100k_equals_stock_and_round_trips(gpu, tmp_path, exe):
-    """`gmix -c` of 100 000 bytes of text: 391 chunks of 2 048 bits through the ring of three batches.  Same compressed
+    """`gmix -c` of 100 000 bytes of text: 391 chunks of 2 048 bits through the ring of batches.  Same compressed
     bytes as the stock build, same analysis tables (1 000 rows whose final-mixer entropy is computed from the
     returned chunks), and the STOCK build's `gmix -d` restores the input from the run-ahead compressor's file.
     gmix_chain_batched: LSTM -> 41 Indirect models -> 33 mixers on the device, each chunk a chain of three batched
