@@ -71,6 +71,7 @@ def test_bench_multi_rank_path_over_rccl(gpu):
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
 
 
+@pytest.mark.gpu
 def test_bench_whole_files_on_every_rank(gpu):
     """bench.py across ranks also compresses whole files on every GPU (64 files per rank on the rank's own device, a
     process per GPU, nothing exchanged but the figures): also.e2e_S64 carries every rank's rate and the aggregate."""
