@@ -405,7 +405,7 @@ def main():
             if name == args.config or (only and name not in only):
                 continue
             try:
-                # two warm-up launches: each of the library's two decay-table slots is allocated before the clock runs
+                # warm-up launches: the library's staging slots (decay tables) are allocated by the first of them
                 r = run_workload(name, comm, local_rank, warmup=2, ring_n=2,
                                  want_cpu=not args.no_cpu_baseline and name != "stock_S1")
             except Exception as e:  # a sub-result must never cost the headline line
