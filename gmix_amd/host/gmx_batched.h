@@ -469,21 +469,42 @@ inline bool BatchedRunTraining(const std::string& checkpoint_path, const std::st
       fflush(stdout);
       if (pos == 0) continue;
       if ((pos / percent % 2) != 0) continue;
+      const bool trace = getenv("GMX_POOL_TRACE") != nullptr;  // where an evaluation's time goes
+      const auto t_a = std::chrono::steady_clock::now();
       rc = trainer.Sync();  // train_entropy is whole up to this byte, and the Predictor can be copied
       if (rc) break;
-      Predictor p2;
+      const auto t_b = std::chrono::steady_clock::now();
+      std::unique_ptr<Predictor> p2_owner(new Predictor());
+      Predictor& p2 = *p2_owner;
+      const auto t_c = std::chrono::steady_clock::now();
       p2.Copy(p);
+      const auto t_d = std::chrono::steady_clock::now();
       BatchedOptions quiet = opt;
       quiet.analysis = false;
-      BatchedScorer scorer(&p2, quiet);
-      rc = scorer.Begin();
-      data_test.seekg(0, std::ios::beg);
-      for (unsigned int pos2 = 0; rc == GMX_OK && pos2 < test_bytes; ++pos2) {
-        scorer.ScoreByte(data_test.get());
-        rc = scorer.status();
+      double test_entropy = 0;
+      std::chrono::steady_clock::time_point t_e, t_f;
+      {
+        BatchedScorer scorer(&p2, quiet);
+        rc = scorer.Begin();
+        t_e = std::chrono::steady_clock::now();
+        data_test.seekg(0, std::ios::beg);
+        for (unsigned int pos2 = 0; rc == GMX_OK && pos2 < test_bytes; ++pos2) {
+          scorer.ScoreByte(data_test.get());
+          rc = scorer.status();
+        }
+        if (rc == GMX_OK) rc = scorer.End();
+        t_f = std::chrono::steady_clock::now();
+        test_entropy = scorer.log2_sum();
       }
-      if (rc == GMX_OK) rc = scorer.End();
-      const double test_entropy = scorer.log2_sum();
+      p2_owner.reset();
+      if (trace) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+          return std::chrono::duration<double>(b - a).count() * 1e3;
+        };
+        fprintf(stderr, "[gmx train] evaluation at %u: sync %.0f, Predictor() %.0f, Copy %.0f, Begin %.0f, scoring %.0f, "
+                        "~Predictor %.0f ms\n", pos, ms(t_a, t_b), ms(t_b, t_c), ms(t_c, t_d), ms(t_d, t_e), ms(t_e, t_f),
+                ms(t_f, std::chrono::steady_clock::now()));
+      }
       metrics << std::fixed << std::setprecision(5) << pos << "\t" << -train_entropy / pos << "\t"
               << -test_entropy / test_bytes << std::endl;
     }

@@ -757,7 +757,8 @@ class GpuMixerBank {
     const char* p = l.data();
     for (size_t j = 0; j < descs_.size(); ++j) {
       auto& table = ltm_.mixers[memory_index_[j]].mixer_table;
-      for (auto& row : table) row.reset();
+      table.clear();  // (rows of an earlier staging go; the vector is sized for the reference's writers)
+      table.resize(descs_[j].table_size);
       uint32_t n, input_size;
       memcpy(&n, p, 4);
       memcpy(&input_size, p + 4, 4);
@@ -775,11 +776,30 @@ class GpuMixerBank {
     staged_ = true;
   }
   // The staged rows are only for the serialisers: give the host memory back once the stream moves on.
+  // LongTermMemory::mixers[..].mixer_table holds one pointer per gate-table row (the stock tables: ~10^8 rows, most
+  // of a gigabyte of pointers) which the reference's Mixer fills as contexts are seen.  Here the rows live on the
+  // device, so the vectors stay EMPTY except around the reference's own serialisers -- sized before
+  // LongTermMemory::ReadFromDisk (which keeps a table's size, long-term-memory.cpp:133-137) and while staged for
+  // WriteToDisk.  (LongTermMemory::Copy then has nothing to clear, allocate and walk for them: a Predictor::Copy
+  // took 0.9 s, most of it there.)
+  void HostTables(bool on) {
+    for (size_t j = 0; j < descs_.size(); ++j) {
+      auto& table = ltm_.mixers[memory_index_[j]].mixer_table;
+      if (on) {
+        if (table.size() != descs_[j].table_size) {
+          table.clear();
+          table.resize(descs_[j].table_size);
+        }
+      } else {
+        std::vector<std::unique_ptr<MixerData>>().swap(table);
+      }
+    }
+  }
   void Unstage() {
-    if (!staged_ || import_pending_) return;
+    if (import_pending_) return;
+    if (!staged_ && (descs_.empty() || ltm_.mixers[memory_index_[0]].mixer_table.empty())) return;
     staged_ = false;
-    for (size_t j = 0; j < descs_.size(); ++j)
-      for (auto& row : ltm_.mixers[memory_index_[j]].mixer_table) row.reset();
+    HostTables(false);
   }
   void PredictAll(ShortTermMemory& stm);
   void LearnAll(const ShortTermMemory& stm) {
@@ -818,6 +838,7 @@ class GpuMixerBank {
     if (o.st().ra) o.SyncRunAhead();
     if (st().ra) SyncRunAhead();
     o.Settle();
+    o.Unstage();  // (LongTermMemory::Copy, which follows, would copy staged rows one by one)
     Ensure();
     import_pending_ = false;  // whatever LongTermMemory::Copy moves into the staging area is not ours to import
     ever_ran_ = true;
@@ -888,7 +909,7 @@ class GpuMixer : public Model {
     // mixer.cpp:12-15: the registrations Mixer::Mixer makes
     const int output_index = short_term_memory.AddMixer(description, layer_number, enable_analysis, this);
     int memory_index = (int)long_term_memory.mixers.size();
-    long_term_memory.mixers.push_back(MixerMemory(table_size));
+    long_term_memory.mixers.push_back(MixerMemory(0));  // (no host rows: GpuMixerBank::HostTables)
     int weight_size;  // mixer.cpp:17-26
     if (layer_number == 0)
       weight_size = short_term_memory.num_predictions + output_index;
@@ -918,6 +939,7 @@ class GpuMixer : public Model {
     bank_->Ensure();
     s->read(&bank_->short_in_[24 * (size_t)index_], 24);
     bank_->import_pending_ = true;
+    if (index_ == 0) bank_->HostTables(true);  // LongTermMemory::ReadFromDisk comes next (predictor.cpp:412-416) and fills them
   }
   // mixer.cpp:190-195 (+ the mixers' share of LongTermMemory::Copy, long-term-memory.cpp:201-214)
   void Copy(const MemoryInterface* m) override {
