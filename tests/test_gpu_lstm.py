@@ -34,7 +34,22 @@ def run_gpu(gpu, g, streams, chunk, learn=True):
     return P, A, Cx
 
 
-def test_lstm_kernel_equals_oracle_through_backward_passes(gpu, oracle):
+@pytest.fixture(params=["1", "2"], ids=["one_workgroup_per_cu_build", "two_per_cu_build"])
+def lstm_build(request):
+    """The batched LSTM kernel has a build for launches of at most one workgroup per CU (<= 256 streams: every launch
+    of these tests) and one for more streams (what bench.py's 1 024 streams run): GMX_LSTM_BUILD, read by the launcher
+    at every launch, puts each test through both."""
+    import os
+    old = os.environ.get("GMX_LSTM_BUILD")
+    os.environ["GMX_LSTM_BUILD"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("GMX_LSTM_BUILD", None)
+    else:
+        os.environ["GMX_LSTM_BUILD"] = old
+
+
+def test_lstm_kernel_equals_oracle_through_backward_passes(gpu, oracle, lstm_build):
     S, N = 3, 450                       # four backward passes + Adam steps, launches that split them
     refs, streams = [], []
     for s in range(S):
@@ -114,7 +129,7 @@ def test_lstm_generation_matches_reference_golden(gpu, oracle):
 
 
 @pytest.mark.parametrize("name", ["lstm_short", "lstm_alphabet16", "lstm_long", "lstm_update_limit"])
-def test_lstm_kernel_matches_reference_goldens(gpu, oracle, name):
+def test_lstm_kernel_matches_reference_goldens(gpu, oracle, name, lstm_build):
     """The fixtures made from the REAL reference LstmModel (tests/golden/lstm_*.npz), replayed
     through the HIP path from the seed: dumped bit predictions, the checksum over every bit, the
     hash of the learned weights and output layer."""
