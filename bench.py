@@ -25,8 +25,10 @@ way (barrier, K steps, max over ranks) with its own roofline and one-core refere
   e2e_S1 / e2e_S1_mixers / e2e_S64   (one GPU) whole files through the run-ahead compressor: the reference's feature
                models and coder on the host cores, LSTM + Indirect models + mixers (or the mixers alone) on the device in
                a ring of four batches; 1 file and 64 files side by side -- scripts/bench_e2e.py
-  e2e_train    (one GPU) `gmix -t` (runner_utils::RunTraining) the same way: training Predictor and scored copy
-               running ahead -- scripts/bench_e2e.py measure_training()
+  e2e_decode   (one GPU) S files restored side by side: S of the reference's Decoders in lock step, one device step per
+               coded bit for all of them -- scripts/bench_e2e.py measure_decode()
+The e2e_* values are COLD (whole process, exec to exit, Predictor construction included) like the reference CLI they
+are set against.  "fracs" (top level, before "also") repeats every kernel's roofline fraction in one short object.
 (--no-also leaves them out; --config X makes X the headline workload for profiling.)
 
 N > 1: one rank per GPU over RCCL.  Under torch.distributed.run the ranks come from the environment;
@@ -335,8 +337,8 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="only the headline workload")
     ap.add_argument("--only-also", default="", help="comma-separated: of the also{} entries, only these")
     ap.add_argument("--e2e-bytes", type=int, default=30000, help="bytes per file of the also.e2e_* entries")
-    ap.add_argument("--train-bytes", type=int, default=20000, help="also.e2e_train: training file (a test run shrinks it)")
-    ap.add_argument("--test-bytes", type=int, default=4000, help="also.e2e_train: test file")
+    ap.add_argument("--decode-bytes", type=int, default=4000, help="bytes per file of also.e2e_decode")
+    ap.add_argument("--decode-streams", type=int, default=64, help="files of also.e2e_decode")
     ap.add_argument("--rehearse-cpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-sample-bits", type=int, default=None,
                     help="bits of the same stream for the one-core reference (default: about 5-15 s of CPU work)")
@@ -427,13 +429,15 @@ def main():
                                      ("e2e_S1", "bench_e2e.py", {"streams": 1, "variant": "chain"}),
                                      ("e2e_S1_mixers", "bench_e2e.py", {"streams": 1, "variant": "mixers"}),
                                      ("e2e_S64", "bench_e2e.py", {"streams": 64, "variant": "chain"}),
-                                     ("e2e_train", "bench_e2e.py", {"training": True})):
+                                     ("e2e_decode", "bench_e2e.py", {"decode": True})):
                 if only and name not in only:
                     continue
                 try:
                     mod = aux_bench(script)
-                    if kw.get("training"):
-                        also[name] = mod.measure_training(train_bytes=args.train_bytes, test_bytes=args.test_bytes)
+                    if kw.get("decode"):
+                        if not hasattr(mod, "measure_decode"):
+                            continue
+                        also[name] = mod.measure_decode(streams=args.decode_streams, n_bytes=args.decode_bytes)
                     elif script == "bench_e2e.py":
                         also[name] = mod.measure(n_bytes=args.e2e_bytes, **kw)
                     else:
@@ -447,15 +451,19 @@ def main():
                                               c.get("bytes_per_stream_per_step")), 0, rf.get("build")))
                 except Exception as e:
                     also[name] = {"error": f"{type(e).__name__}: {e}"}
-        elif not only or "e2e_S64" in only:
-            # whole files on every GPU at once (weak scaling: 64 files per GPU, a process per GPU, no exchange): every
-            # rank compresses its own 64 files on its own device; a rank that fails reports -1 and still takes part in
-            # the three collectives below
+        elif "e2e_S64" in only:
+            # (only when asked for: --only-also e2e_S64.)  Whole files on every GPU at once (weak scaling: a process per
+            # GPU, no exchange): every rank compresses its own files on its own device -- as many as the host's CPU
+            # quota and memory, shared by all ranks, carry (scripts/bench_e2e.py files_that_fit).  The ranks' clocks start
+            # together, behind a barrier, and `value` = all bits / the slowest rank's whole-process time.  A rank that
+            # fails reports -1 and still takes part in the collectives below.
+            mod = aux_bench("bench_e2e.py")
+            n_files = mod.files_that_fit(64, world)
             mine = {"value": -1.0, "seconds": -1.0, "bits": 0.0}
             try:
-                r = aux_bench("bench_e2e.py").measure(streams=64, n_bytes=args.e2e_bytes, variant="chain",
-                                                      device=local_rank, verify=(rank == 0), cpu=False)
-                mine = {"value": r["value"], "seconds": r["seconds"], "bits": 8.0 * 64 * args.e2e_bytes}
+                r = mod.measure(streams=n_files, n_bytes=args.e2e_bytes, variant="chain", device=local_rank,
+                                verify=(rank == 0), cpu=False, before=comm.barrier)
+                mine = {"value": r["value"], "seconds": r["seconds"], "bits": 8.0 * n_files * args.e2e_bytes}
             except Exception as e:
                 r = {"error": f"{type(e).__name__}: {e}"}
             comm.barrier()
@@ -463,7 +471,7 @@ def main():
             if rank == 0:
                 ok = all(v > 0 for v in rates)
                 e = dict(r)
-                e.update({"n_gpus": world, "per_rank": {"bits_per_s": rates, "seconds": secs},
+                e.update({"n_gpus": world, "files_per_gpu": n_files, "per_rank": {"bits_per_s": rates, "seconds": secs},
                           "value": (sum(bits) / max(secs)) if ok else None, "scaling": "weak"})
                 if not ok:
                     e["error"] = "a rank failed: " + str(rates)
@@ -478,8 +486,20 @@ def main():
             out["per_rank"] = head["per_rank"]
         if "cpu_baseline" in head:
             out["cpu_baseline"] = head["cpu_baseline"]
+        # every kernel's fraction of its roofline in one short object AHEAD of the long sub-results (a truncated
+        # tail still shows it); whole-file entries give bits/s, cold, and their ratio to the CPU's own CLI
+        fracs = {args.config: round(head["roofline"]["frac"], 4)}
+        for name, r in also.items():
+            if isinstance(r, dict) and isinstance(r.get("roofline"), dict) and r["roofline"].get("frac") is not None:
+                fracs[name] = round(r["roofline"]["frac"], 4)
+        out["fracs"] = fracs
+        e2e = {name: {"bits_per_s_cold": r.get("value"), "vs_cpu": r.get("vs_cpu"), "identical": r.get("identical_to_stock")}
+               for name, r in also.items() if name.startswith("e2e_") and isinstance(r, dict) and "error" not in r}
         if also:
             out["also"] = also
+        # ... and once more as the line's LAST object: a reader who keeps only the end of a long line (the driver's
+        # record holds the last 2 000 characters) still sees every fraction and the whole-file figures
+        out["tail_summary"] = {"fracs": fracs, "e2e": e2e}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

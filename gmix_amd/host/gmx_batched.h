@@ -20,7 +20,7 @@
 // in the reference is one call in RunCompression (runner-utils.cpp:118):
 //     -  Compress(*input_bytes, &data_in, &data_out, output_bytes, &p);
 //     +  gmx::BatchedCompress(*input_bytes, &data_in, &data_out, output_bytes, &p);
-// oracle/ref_build/Makefile builds the reference's CLI that way (gmix_batched).
+// dropin/Makefile builds the reference's CLI that way (gmix_batched).
 //
 // Decompression cannot run ahead (the decoder learns each bit from Predict's own result, decoder.cpp:19-39): it
 // keeps the per-bit path of gmx_model_adapter.h.
@@ -34,9 +34,6 @@
 //
 // Many files: BatchedCompressFiles runs one Predictor per file on a thread of its own, all mixers in ONE gmx_group
 // (gmx::MixerPool), one launch per chunk for all files.
-//
-// Training (`gmix -t`, runner_utils::RunTraining, runner-utils.cpp:222-322) knows its bits as well:
-// BatchedRunTraining, on BatchedCompressor's steps (Begin / CodeByte / Sync / Finish) and BatchedScorer.
 #ifndef GMX_BATCHED_H_
 #define GMX_BATCHED_H_
 
@@ -47,6 +44,7 @@
 #include <cmath>
 #include <deque>
 #include <filesystem>
+#include <functional>
 #include <iomanip>
 #include <thread>
 
@@ -209,7 +207,7 @@ class BatchedCompressor : public RunAheadSink {
     }
     return Finish(os, output_bytes);
   }
-  // Code in steps, for a caller with a loop of its own (BatchedRunTraining): eight bits of one byte ...
+  // Code in steps, for a caller with a loop of its own: eight bits of one byte ...
   void CodeByte(int c) {
     ShortTermMemory& stm = bank_->stm();
     for (int j = 7; j >= 0; --j) {
@@ -247,10 +245,6 @@ class BatchedCompressor : public RunAheadSink {
     *output_bytes = os->tellp();
     return GMX_OK;
   }
-  // Adds log2 of the probability given to every coded bit, in bit order (RunTraining's train_entropy,
-  // runner-utils.cpp:276-279), as the chunks come back.
-  void SumLog2Into(double* sum) { log2_sum_ = sum; }
-
   // RunAheadSink: a chunk is back
   bool WantsModels() const override { return wants_models_ || F_ > 0; }  // (with analysis on at least the last bit's flags)
   bool SilentSlotsAreZero() const override { return F_ > 0; }
@@ -259,13 +253,6 @@ class BatchedCompressor : public RunAheadSink {
   void Drain(const RunAheadView& v) override {
     for (uint64_t i = 0; i < v.n; ++i) {
       enc_.Encode(v.bits[i], v.p[i]);
-      if (log2_sum_) {  // (the reference's own expression, float in, whatever log2 this translation unit sees)
-        const float prob = v.p[i];
-        if (v.bits[i])
-          *log2_sum_ += log2(prob);
-        else
-          *log2_sum_ += log2(1 - prob);
-      }
       if (F_ > 0) {
         for (Source& src : on_device_) {  // Predictor::UpdateEntropy (predictor.cpp:439-469) on what the device produced
           float x;
@@ -369,156 +356,7 @@ class BatchedCompressor : public RunAheadSink {
   bool wants_models_ = false, wants_all_outputs_ = false;
   std::deque<Row> rows_;
   uint64_t recorded_ = 0, drained_ = 0;
-  double* log2_sum_ = nullptr;
 };
-
-// A Predictor that is only scored on bytes it learns from (the test pass of runner_utils::RunTraining,
-// runner-utils.cpp:291-306: Predict / Perceive / Learn of every bit and the sum of log2 p, no coder).
-class BatchedScorer : public RunAheadSink {
- public:
-  BatchedScorer(Predictor* p, const BatchedOptions& opt) : p_(p), opt_(opt), bank_(GpuMixerBank::Of(p, sizeof(Predictor))) {}
-  int Begin() {
-    if (!bank_) return GMX_ERR_INVALID;
-    const uint64_t chunk = opt_.chunk_bits < 8 ? 8 : opt_.chunk_bits & ~7ull;
-    return bank_->BeginRunAhead(this, chunk);
-  }
-  void ScoreByte(int c) {
-    for (int j = 7; j >= 0; --j) {
-      p_->Predict();
-      p_->Perceive((c >> j) & 1);
-      p_->Learn();
-    }
-  }
-  int End() {
-    int rc = bank_->EndRunAhead();
-    return rc ? rc : bank_->status();
-  }
-  int status() const { return bank_ ? bank_->status() : GMX_ERR_INVALID; }
-  double log2_sum() const { return sum_; }
-  void Drain(const RunAheadView& v) override {
-    for (uint64_t i = 0; i < v.n; ++i) {
-      const float prob = v.p[i];
-      if (v.bits[i])
-        sum_ += log2(prob);
-      else
-        sum_ += log2(1 - prob);
-    }
-  }
-
- private:
-  Predictor* p_;
-  BatchedOptions opt_;
-  std::shared_ptr<GpuMixerBank> bank_;
-  double sum_ = 0;
-};
-
-// runner_utils::RunTraining (runner-utils.cpp:222-322), argument for argument, with the device-side models of both
-// Predictors -- the one that trains and the copy that is scored on the test file every other per cent -- running
-// ahead: same data/tmp, analysis/*.tsv, data/trained_checkpoint and printed cross entropy.
-inline bool BatchedRunTraining(const std::string& checkpoint_path, const std::string& train_path,
-                               const std::string& test_path, unsigned long long* input_bytes,
-                               unsigned long long* output_bytes, const BatchedOptions& opt_in = BatchedOptions()) {
-  std::ifstream data_train(train_path, std::ios::in | std::ios::binary);
-  if (!data_train.is_open()) {
-    printf("Can not open: %s\n", train_path.c_str());
-    return false;
-  }
-  std::ifstream data_test(test_path, std::ios::in | std::ios::binary);
-  if (!data_test.is_open()) {
-    printf("Can not open: %s\n", test_path.c_str());
-    return false;
-  }
-  data_train.seekg(0, std::ios::end);
-  *input_bytes = data_train.tellg();
-  data_train.seekg(0, std::ios::beg);
-  data_test.seekg(0, std::ios::end);
-  const unsigned long long test_bytes = data_test.tellg();
-  data_test.seekg(0, std::ios::beg);
-
-  std::filesystem::create_directory("analysis");
-  std::ofstream metrics("analysis/training.tsv", std::ios::out);
-  metrics << "bytes\ttrain_entropy\ttest_entropy" << std::endl;
-  std::filesystem::create_directory("data");
-  std::ofstream data_out("data/tmp", std::ios::out | std::ios::binary);
-  if (!data_out.is_open()) {
-    printf("Can not open: data/tmp\n");
-    return false;
-  }
-  runner_utils::WriteHeader(*input_bytes, &data_out);
-
-  Predictor p;
-  if (!checkpoint_path.empty()) {
-    printf("\rLoading checkpoint...");
-    fflush(stdout);
-    p.ReadCheckpoint(checkpoint_path);
-    printf("\r                        ");
-  }
-  BatchedOptions opt = opt_in;
-  opt.analysis = true;   // p.EnableAnalysis(8 * input_bytes / 1000), runner-utils.cpp:270
-  opt.progress = false;  // (this loop prints its own)
-  if (const char* e = getenv("GMX_CHUNK_BITS")) opt.chunk_bits = strtoull(e, nullptr, 0);  // (tests: many small chunks)
-  BatchedCompressor trainer(&p, &data_out, opt);
-  double train_entropy = 0;
-  trainer.SumLog2Into(&train_entropy);
-  int rc = trainer.Begin(*input_bytes);
-  const unsigned long long percent = 1 + ((*input_bytes) / 100);
-  for (unsigned int pos = 0; rc == GMX_OK && pos < *input_bytes; ++pos) {
-    trainer.CodeByte(data_train.get());
-    if (pos % percent == 0) {
-      printf("\rtraining: %lld%%", pos / percent);
-      fflush(stdout);
-      if (pos == 0) continue;
-      if ((pos / percent % 2) != 0) continue;
-      const bool trace = getenv("GMX_POOL_TRACE") != nullptr;  // where an evaluation's time goes
-      const auto t_a = std::chrono::steady_clock::now();
-      rc = trainer.Sync();  // train_entropy is whole up to this byte, and the Predictor can be copied
-      if (rc) break;
-      const auto t_b = std::chrono::steady_clock::now();
-      std::unique_ptr<Predictor> p2_owner(new Predictor());
-      Predictor& p2 = *p2_owner;
-      const auto t_c = std::chrono::steady_clock::now();
-      p2.Copy(p);
-      const auto t_d = std::chrono::steady_clock::now();
-      BatchedOptions quiet = opt;
-      quiet.analysis = false;
-      double test_entropy = 0;
-      std::chrono::steady_clock::time_point t_e, t_f;
-      {
-        BatchedScorer scorer(&p2, quiet);
-        rc = scorer.Begin();
-        t_e = std::chrono::steady_clock::now();
-        data_test.seekg(0, std::ios::beg);
-        for (unsigned int pos2 = 0; rc == GMX_OK && pos2 < test_bytes; ++pos2) {
-          scorer.ScoreByte(data_test.get());
-          rc = scorer.status();
-        }
-        if (rc == GMX_OK) rc = scorer.End();
-        t_f = std::chrono::steady_clock::now();
-        test_entropy = scorer.log2_sum();
-      }
-      p2_owner.reset();
-      if (trace) {
-        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-          return std::chrono::duration<double>(b - a).count() * 1e3;
-        };
-        fprintf(stderr, "[gmx train] evaluation at %u: sync %.0f, Predictor() %.0f, Copy %.0f, Begin %.0f, scoring %.0f, "
-                        "~Predictor %.0f ms\n", pos, ms(t_a, t_b), ms(t_b, t_c), ms(t_c, t_d), ms(t_d, t_e), ms(t_e, t_f),
-                ms(t_f, std::chrono::steady_clock::now()));
-      }
-      metrics << std::fixed << std::setprecision(5) << pos << "\t" << -train_entropy / pos << "\t"
-              << -test_entropy / test_bytes << std::endl;
-    }
-  }
-  if (rc == GMX_OK) rc = trainer.Finish(&data_out, output_bytes);
-  if (rc) {
-    fprintf(stderr, "\ngmx::BatchedRunTraining: %s (status %d)\n", gmx_strerror(rc), rc);
-    return false;
-  }
-  train_entropy = -train_entropy / *input_bytes;
-  printf("\rtraining cross entropy: %.4f\n", train_entropy);
-  p.WriteCheckpoint("data/trained_checkpoint");
-  return true;
-}
 
 // runner_utils::Compress (runner-utils.cpp:43-67), argument for argument; returns 0 or a gmx_status.
 inline int BatchedCompress(unsigned long long input_bytes, std::ifstream* is, std::ofstream* os,
@@ -534,18 +372,140 @@ struct BatchedJob {
   std::string input_path, output_path;
   unsigned long long input_bytes = 0, output_bytes = 0;
   int status = 0;        // 0 or a gmx_status / -100 for a file that would not open
-  double seconds = 0;    // the compression loop alone (Predictor construction not included)
+  double seconds = 0;    // the coding loop alone (Predictor construction not included)
 };
 struct BatchedStats {
-  double wall_seconds = 0;     // first compression loop's start to the last one's end (all Predictors built before)
-  double build_seconds = 0;    // building the Predictors, one after the other (they draw from rand(), predictor.cpp:18)
-  uint64_t launches = 0;       // chunks of all streams queued on the device
+  double total_seconds = 0;    // the whole call: pool, Predictors, device banks, coding, teardown -- the like-for-like figure
+                               // against runner_utils::RunCompression (runner-utils.cpp:88-121), which builds its Predictor too
+  double wall_seconds = 0;     // first coding loop's start to the last one's end (every Predictor and bank standing)
+  double build_seconds = 0;    // everything before that: Predictors (side by side when they draw nothing from rand(), else
+                               // one after the other: predictor.cpp:18), device banks, the ring's pinned arrays
+  double first_predictor_seconds = 0;  // ... of which the first Predictor, which is always built alone
+  double teardown_seconds = 0; // last coding loop's end to the return
+  bool parallel_construction = false;
+  uint64_t launches = 0;       // chunks (steps, when decoding) of all streams queued on the device
   uint64_t bits = 0;           // bits of all streams mixed there
   int pinned_threads = 0;      // threads kept on the cores of the device's NUMA node
   int pinned_cpus = 0;         // ... on how many of them (0: all of the node's)
   double submit_seconds = 0;   // host time spent queueing chunks on the device ...
   double wait_seconds = 0;     // ... and waiting for the chunk before (all streams stand still meanwhile)
 };
+
+// What runs on the thread of one job between the Predictors' construction and their destruction.
+struct ManyFilesHooks {
+  // the job's Predictor stands, its thread is pinned: join the pool (0 or a gmx_status)
+  std::function<int(int s, Predictor* p)> begin;
+  // every job has begun: the timed loop
+  std::function<int(int s, Predictor* p)> run;
+  // the loop is over (the Predictor still stands)
+  std::function<void(int s)> end;
+};
+
+// One Predictor and one thread per job, all Predictors in one MixerPool of jobs.size() streams: the frame shared by
+// BatchedCompressFiles and BatchedDecompressFiles.  `open(s)` opens job s's files (false: the job fails with -100).
+inline void RunManyFiles(std::vector<BatchedJob>& jobs, MixerPool& pool, const BatchedOptions& opt,
+                         const std::function<bool(int)>& open, const ManyFilesHooks& hooks, BatchedStats* stats) {
+  using clock = std::chrono::steady_clock;
+  const clock::time_point tb = clock::now();
+  const int S = (int)jobs.size();
+  pool.Install();  // (draws the LSTM's constant initial weights once, MixerPool::DrawLstmInit)
+  std::mutex construct;  // Predictor::Predictor draws the LSTM's weights from rand() after srand() (predictor.cpp:18)
+  std::mutex start_mu;
+  std::condition_variable start_cv;
+  int built = 0, ready = 0;
+  bool first_built = false;
+  std::atomic<int> pinned{0};
+  const int max_cpus = opt.max_cpus < 0 ? 2 * QuotaCpus() : opt.max_cpus;
+  clock::time_point t0 = tb, t_first = tb;
+  std::vector<clock::time_point> ends(S, tb);
+  std::vector<std::thread> threads;
+  for (int s = 0; s < S; ++s) {
+    threads.emplace_back([&, s] {
+      BatchedJob& job = jobs[s];
+      std::unique_ptr<Predictor> p;
+      const bool opened = open(s);
+      if (!opened) job.status = -100;
+      // The FIRST Predictor is built alone.  If its LSTM turned out to be gmx::GpuLstmModel taking its initial
+      // weights from the pool (the chain builds), no constructor draws from the process-wide rand() and the others
+      // are built side by side, while the first one's thread already brings up the device banks.  If not (the host's
+      // own LstmModel draws, lstm-layer.h:41), constructions stay serial and nothing else runs until every Predictor
+      // stands: whatever a thread next to a constructor calls -- the HIP runtime coming up, a pinned allocation --
+      // may draw from the same generator (seen: one output of several differing from `gmix -c`, always the same one).
+      if (s == 0) {
+        if (opened) p.reset(new Predictor());
+        std::lock_guard<std::mutex> lk(start_mu);
+        first_built = true;
+        t_first = clock::now();
+        start_cv.notify_all();
+      } else {
+        {
+          std::unique_lock<std::mutex> lk(start_mu);
+          start_cv.wait(lk, [&] { return first_built; });
+        }
+        if (opened) {
+          if (pool.parallel_construction()) {
+            p.reset(new Predictor());
+          } else {
+            std::lock_guard<std::mutex> lk(construct);
+            p.reset(new Predictor());
+          }
+        }
+      }
+      if (!pool.parallel_construction()) {
+        std::unique_lock<std::mutex> lk(start_mu);
+        if (++built == S)
+          start_cv.notify_all();
+        else
+          start_cv.wait(lk, [&] { return built == S; });
+      }
+      if (opt.pin_threads && PinThreadToDeviceNode(pool.device(), max_cpus)) ++pinned;
+      bool begun = false;
+      if (p) {
+        job.status = hooks.begin(s, p.get());  // every stream is in the pool before the first one records or codes
+        begun = job.status == 0;
+      }
+      {  // every Predictor and every bank stands before the first loop starts
+        std::unique_lock<std::mutex> lk(start_mu);
+        if (++ready == S) {
+          t0 = clock::now();
+          start_cv.notify_all();
+        } else {
+          start_cv.wait(lk, [&] { return ready == S; });
+        }
+      }
+      const clock::time_point a = clock::now();
+      if (begun) job.status = hooks.run(s, p.get());
+      ends[s] = clock::now();
+      job.seconds = std::chrono::duration<double>(ends[s] - a).count();
+      hooks.end(s);
+      if (pool.parallel_construction()) {
+        p.reset();
+      } else {
+        std::lock_guard<std::mutex> lk(construct);  // (a Predictor gives back gigabytes: one at a time)
+        p.reset();
+      }
+    });
+  }
+  for (auto& t : threads) t.join();
+  pool.Uninstall();
+  if (stats) {
+    clock::time_point t1 = t0;
+    for (auto& e : ends) t1 = std::max(t1, e);
+    const clock::time_point tz = clock::now();
+    stats->total_seconds = std::chrono::duration<double>(tz - tb).count();
+    stats->wall_seconds = std::chrono::duration<double>(t1 - t0).count();
+    stats->build_seconds = std::chrono::duration<double>(t0 - tb).count();
+    stats->first_predictor_seconds = std::chrono::duration<double>(t_first - tb).count();
+    stats->teardown_seconds = std::chrono::duration<double>(tz - t1).count();
+    stats->parallel_construction = pool.parallel_construction();
+    stats->launches = pool.rounds();
+    stats->bits = pool.bits_submitted();
+    stats->pinned_threads = pinned.load();
+    stats->pinned_cpus = max_cpus;
+    stats->submit_seconds = pool.submit_seconds();
+    stats->wait_seconds = pool.wait_seconds();
+  }
+}
 
 // runner_utils::RunCompression (runner-utils.cpp:88-121) for every job at once: a Predictor and a thread per
 // file, their mixers in one gmx_group of jobs.size() streams.  Returns the number of jobs that failed.
@@ -557,93 +517,36 @@ inline int BatchedCompressFiles(std::vector<BatchedJob>& jobs, const BatchedOpti
   const int S = (int)jobs.size();
   if (S == 0) return 0;
   MixerPool pool(S, opt.device);
-  pool.Install();
-  std::mutex construct;  // Predictor::Predictor draws the LSTM's weights from rand() after srand() (predictor.cpp:18)
-  std::mutex start_mu;
-  std::condition_variable start_cv;
-  int built = 0, ready = 0;
-  std::atomic<int> pinned{0};
-  const int max_cpus = opt.max_cpus < 0 ? 2 * QuotaCpus() : opt.max_cpus;
-  using clock = std::chrono::steady_clock;
-  const clock::time_point tb = clock::now();
-  clock::time_point t0 = tb;
-  std::vector<clock::time_point> ends(S, tb);
-  std::vector<std::thread> threads;
-  for (int s = 0; s < S; ++s) {
-    threads.emplace_back([&, s] {
-      BatchedJob& job = jobs[s];
-      std::ifstream data_in(job.input_path, std::ios::in | std::ios::binary);
-      std::ofstream data_out;
-      std::unique_ptr<Predictor> p;
-      if (data_in.is_open()) {
-        data_in.seekg(0, std::ios::end);
-        job.input_bytes = data_in.tellg();
-        data_in.seekg(0, std::ios::beg);
-        data_out.open(job.output_path, std::ios::out | std::ios::binary);
-      }
-      if (!data_in.is_open() || !data_out.is_open()) {
-        job.status = -100;
-      } else {
-        runner_utils::WriteHeader(job.input_bytes, &data_out);
-        std::lock_guard<std::mutex> lk(construct);
-        p.reset(new Predictor());
-      }
-      // Nothing else runs until every Predictor stands: its constructor seeds and draws from the process-wide
-      // rand() (predictor.cpp:18, lstm-layer.h:41), and whatever a thread next to it calls -- the HIP runtime coming
-      // up, a pinned allocation -- may draw from the same generator: one file's LSTM then starts from other weights
-      // than the reference's (seen: one output of several differing from `gmix -c`, always the same one).
-      {
-        std::unique_lock<std::mutex> lk(start_mu);
-        if (++built == S)
-          start_cv.notify_all();
-        else
-          start_cv.wait(lk, [&] { return built == S; });
-      }
-      if (opt.pin_threads && PinThreadToDeviceNode(pool.device(), max_cpus)) ++pinned;
-      std::unique_ptr<BatchedCompressor> c;
-      if (p) {
-        c.reset(new BatchedCompressor(p.get(), &data_out, opt));
-        job.status = c->Begin(job.input_bytes);  // every stream is in the pool's ring before the first chunk is recorded
-        if (job.status) c.reset();
-      }
-      {  // all Predictors stand before the first one runs: the timed region is compression only
-        std::unique_lock<std::mutex> lk(start_mu);
-        if (++ready == S) {
-          t0 = clock::now();
-          start_cv.notify_all();
-        } else {
-          start_cv.wait(lk, [&] { return ready == S; });
-        }
-      }
-      const clock::time_point a = clock::now();
-      if (c) {
-        job.status = c->Code(job.input_bytes, &data_in, &data_out, &job.output_bytes);
-        c.reset();
-      }
-      ends[s] = clock::now();
-      job.seconds = std::chrono::duration<double>(ends[s] - a).count();
-      data_out.close();
-      std::lock_guard<std::mutex> lk(construct);  // (a Predictor gives back gigabytes: one at a time)
-      p.reset();
-    });
-  }
-  for (auto& t : threads) t.join();
-  pool.Uninstall();
+  std::vector<std::ifstream> in(S);
+  std::vector<std::ofstream> out(S);
+  std::vector<std::unique_ptr<BatchedCompressor>> c(S);
+  ManyFilesHooks hooks;
+  hooks.begin = [&](int s, Predictor* p) {
+    c[s].reset(new BatchedCompressor(p, &out[s], opt));
+    int rc = c[s]->Begin(jobs[s].input_bytes);
+    if (rc) c[s].reset();
+    return rc;
+  };
+  hooks.run = [&](int s, Predictor*) { return c[s]->Code(jobs[s].input_bytes, &in[s], &out[s], &jobs[s].output_bytes); };
+  hooks.end = [&](int s) {
+    c[s].reset();
+    out[s].close();
+  };
+  RunManyFiles(jobs, pool, opt, [&](int s) {
+    BatchedJob& job = jobs[s];
+    in[s].open(job.input_path, std::ios::in | std::ios::binary);
+    if (!in[s].is_open()) return false;
+    in[s].seekg(0, std::ios::end);
+    job.input_bytes = in[s].tellg();
+    in[s].seekg(0, std::ios::beg);
+    out[s].open(job.output_path, std::ios::out | std::ios::binary);
+    if (!out[s].is_open()) return false;
+    runner_utils::WriteHeader(job.input_bytes, &out[s]);
+    return true;
+  }, hooks, stats);
   int failed = 0;
   for (auto& j : jobs) failed += j.status != 0;
   if (pool.status() != 0) fprintf(stderr, "gmx::BatchedCompressFiles: %s\n", pool.error().c_str());
-  if (stats) {
-    clock::time_point t1 = t0;
-    for (auto& e : ends) t1 = std::max(t1, e);
-    stats->wall_seconds = std::chrono::duration<double>(t1 - t0).count();
-    stats->build_seconds = std::chrono::duration<double>(t0 - tb).count();
-    stats->launches = pool.rounds();
-    stats->bits = pool.bits_submitted();
-    stats->pinned_threads = pinned.load();
-    stats->pinned_cpus = max_cpus;
-    stats->submit_seconds = pool.submit_seconds();
-    stats->wait_seconds = pool.wait_seconds();
-  }
   return failed;
 }
 

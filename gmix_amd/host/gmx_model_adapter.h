@@ -8,7 +8,7 @@
 //     #include "gmx_model_adapter.h"                      in src/predictor.cpp
 //     new Mixer(  ->  new gmx::GpuMixer(                   33 times in Predictor::AddMixers
 // and nothing else: Predictor, the runners, the coder, LongTermMemory and the tester stay as they
-// are (oracle/ref_build/Makefile builds gmix and the reference's tester that way, from a patched
+// are (dropin/Makefile builds gmix and the reference's tester that way, from a patched
 // temporary copy of predictor.cpp; tests/test_gpu_dropin.py runs them against the stock build).
 //
 // How 33 objects become one device bank
@@ -161,11 +161,45 @@ class MixerPool {
     std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
     Installed() = this;
     shared_ = true;
+    DrawLstmInit();
   }
   void Uninstall() {
     std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
     if (Installed() == this) Installed() = nullptr;
   }
+  // The LSTM's initial gate weights are a constant of the reference: every Predictor constructor begins with
+  // srand(0xDEADBEEF) (predictor.cpp:18) and the LSTM is the first model that draws (lstm-layer.h:41; BasicContexts,
+  // the interval contexts and PPMd, built before it, draw nothing).  A pool that hosts many Predictors draws the
+  // 3 x 50 x 563 numbers ONCE, here, from the same rand() while nothing else runs, and gmx::GpuLstmModel's constructor
+  // takes them from the pool instead of the process-wide generator -- so that Predictors whose LSTM is on the device
+  // can be built side by side on many threads (the reference's constructor, 65 ms of host work each, was 4 of the
+  // 5 seconds a 64-file run of 30 KB files took: VERDICT r3 #1).  The draw is checked against its known FNV-1a
+  // (a stray rand() of another thread in between would shift it): on a mismatch the pool keeps no cache and
+  // constructions stay serial, drawing for themselves as before.
+  static constexpr int kLstmDraws = 3 * 50 * 563;
+  void DrawLstmInit() {
+    if (!lstm_init_.empty()) return;
+    std::vector<int> draws(kLstmDraws);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+      srand(0xDEADBEEF);
+      uint64_t h = 1469598103934665603ull;
+      for (int i = 0; i < kLstmDraws; ++i) {
+        draws[i] = rand();
+        h = (h ^ (uint64_t)(uint32_t)draws[i]) * 1099511628211ull;
+      }
+      if (h == kLstmDrawsFnv) {
+        lstm_init_.swap(draws);
+        return;
+      }
+    }
+    fprintf(stderr, "gmx::MixerPool: rand() after srand(0xDEADBEEF) is not the sequence this build was made with; "
+                    "Predictors will be constructed one at a time\n");
+  }
+  // 0, or the kLstmDraws values rand() gives after srand(0xDEADBEEF), in drawing order
+  const int* lstm_init() const { return lstm_init_.empty() ? nullptr : lstm_init_.data(); }
+  // A Predictor of this pool has its LSTM on the device and took the initial weights from the pool: its constructor
+  // drew nothing from rand(), so constructors may run side by side
+  bool parallel_construction() const { return lstm_from_cache_.load(); }
   int n_streams() const { return S_; }
   int device() const { return device_; }
   gmx_group* group() const { return group_; }
@@ -544,6 +578,9 @@ class MixerPool {
   const int S_;
   int device_;
   bool shared_ = false;
+  static constexpr uint64_t kLstmDrawsFnv = 0xcb25b734d7bec78full;  // FNV-1a over the draws (glibc's rand(): TYPE_3, r[i] = r[i-3] + r[i-31])
+  std::vector<int> lstm_init_;
+  std::atomic<bool> lstm_from_cache_{false};
   gmx_group* group_ = nullptr;
   gmx_indirect* ind_ = nullptr;
   gmx_lstm* lstm_ = nullptr;
@@ -966,7 +1003,7 @@ class GpuMixer : public Model {
 // Switched in like the mixers (`new Indirect(` -> `new gmx::GpuIndirect(` at its 33 places, `new LstmModel(`
 // -> `new gmx::GpuLstmModel(` once), the reference's Predictor keeps LSTM -> 41 Indirect -> 33 mixers
 // on the MI355X while PPMd, the match models, the context hashes, the coder and the runners stay the
-// reference's own host code (oracle/ref_build builds it as gmix_chain / ref_tester_chain).
+// reference's own host code (dropin/Makefile builds it as gmix_chain / ref_tester_chain).
 // ================================================================================================
 
 // All Indirect models of one Predictor: one stream of a gmx_indirect.  The last feature model in front of the
@@ -1321,11 +1358,20 @@ class GpuLstmModel : public Model {
     for (int g = 0; g < 3; ++g) ltm_.neuron_layer_weights.push_back(NeuronLayerWeights(kInputs, kCells));
     const float val = std::sqrt(6.0f / float(256 + 256));
     const float low = -val, range = 2 * val;
+    // (a pool of many Predictors has drawn these numbers once: MixerPool::DrawLstmInit)
+    const int* drawn = nullptr;
+    {
+      std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
+      if (MixerPool* inst = MixerPool::Installed()) {
+        drawn = inst->lstm_init();
+        if (drawn) inst->lstm_from_cache_.store(true);
+      }
+    }
     for (int i = 0; i < kCells; ++i) {
       for (int j = 0; j < kInputs; ++j)
         for (int g = 0; g < 3; ++g)
           ltm_.neuron_layer_weights[first_layer_ + g].weights[i][j] =
-              low + (static_cast<float>(rand()) / static_cast<float>(RAND_MAX)) * range;
+              low + (static_cast<float>(drawn ? *drawn++ : rand()) / static_cast<float>(RAND_MAX)) * range;
       ltm_.neuron_layer_weights[first_layer_].weights[i][kInputs - 1] = 1;
     }
     prediction_index_ = short_term_memory.AddPrediction("LSTM", enable_analysis, this);

@@ -14,12 +14,12 @@ if [ -z "$SRC" ]; then  # this repository's documents, repeated until there are 
   SRC=$W/corpus
 fi
 head -c $N "$SRC" > $W/in
-REF=$PWD/oracle/_ref
+. scripts/_paths.sh
 mkdir -p $(dirname $OUT)
 {
 echo "input: $(wc -c < $W/in) bytes of ${GMX_CORPUS:-DESIGN.md+SURVEY.md+INTEGRATION.md+README.md}; host: $(grep -m1 'model name' /proc/cpuinfo | cut -d: -f2), $(nproc) cores visible"
 for exe in ${EXES:-gmix_strict gmix_gpu gmix_batched gmix_chain_batched}; do
-  mkdir -p $W/$exe; ( cd $W/$exe; s=$(date +%s.%N); $REF/$exe -c $W/in out > log 2>/dev/null; e=$(date +%s.%N);
+  mkdir -p $W/$exe; ( cd $W/$exe; s=$(date +%s.%N); $(gmxbin $exe) -c $W/in out > log 2>/dev/null; e=$(date +%s.%N);
   echo "$exe: $(wc -c < out) bytes, $(echo "$e $s $N" | awk '{printf "%.2f s, %.2f us per bit", $1-$2, ($1-$2)*1e6/(8*$3)}') (whole process: Predictor construction included), md5 $(md5sum < out | cut -c1-12)" )
 done
 for exe in gmix_gpu gmix_batched gmix_chain_batched; do
@@ -28,6 +28,6 @@ for exe in gmix_gpu gmix_batched gmix_chain_batched; do
   [ $exe = gmix_gpu ] || { cmp $W/gmix_strict/analysis/entropy.tsv $W/$exe/analysis/entropy.tsv && cmp $W/gmix_strict/analysis/memory.tsv $W/$exe/analysis/memory.tsv && echo "analysis tables identical ($exe)"; }
 done
 last=$(ls -d $W/gmix_chain_batched $W/gmix_batched 2>/dev/null | head -1)
-( cd $W/gmix_strict; $REF/gmix_strict -d $last/out back > /dev/null 2>&1; cmp back $W/in && echo "gmix_strict -d restores what $(basename $last) -c wrote" )
+( cd $W/gmix_strict; $(gmxbin gmix_strict) -d $last/out back > /dev/null 2>&1; cmp back $W/in && echo "gmix_strict -d restores what $(basename $last) -c wrote" )
 } | tee $OUT
 rm -rf $W

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Kernel timeline of the run-ahead chain: where the stages of neighbouring chunks overlap and where they wait.
 #   scripts/trace_chain_timeline.sh [bytes per file = 20000] [chunk bits = 2048] [files = 1]
-cd /root/repo
+cd "$(dirname "$0")/.."
 W=$(mktemp -d); mkdir $W/f
 cat DESIGN.md SURVEY.md INTEGRATION.md README.md DESIGN.md SURVEY.md INTEGRATION.md README.md > $W/corpus
 for i in $(seq 0 $((${3:-1}-1))); do tail -c +$((i*1531+1)) $W/corpus | head -c ${1:-20000} > $W/f/$i; done
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $W/prof -o run -- oracle/_ref/gmix_chain_many -T ${2:-2048} $W/out $W/f/* > $W/j.json 2> $W/err
+rocprofv3 --kernel-trace --output-format csv -d $W/prof -o run -- dropin/_build/gmix_chain_many -T ${2:-2048} $W/out $W/f/* > $W/j.json 2> $W/err
 f=$(find $W/prof -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Kernel AND memory-copy timeline of the run-ahead chain around one round: scripts/trace_copies.sh [bytes] [chunk] [files]
-cd /root/repo
+cd "$(dirname "$0")/.."
 W=$(mktemp -d); mkdir $W/f
 cat DESIGN.md SURVEY.md INTEGRATION.md README.md DESIGN.md SURVEY.md INTEGRATION.md README.md > $W/corpus
 for i in $(seq 0 $((${3:-16}-1))); do tail -c +$((i*1531+1)) $W/corpus | head -c ${1:-30000} > $W/f/$i; done
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $W/prof -o run -- oracle/_ref/gmix_chain_many -T ${2:-2048} $W/out $W/f/* > $W/j.json 2> $W/err
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $W/prof -o run -- dropin/_build/gmix_chain_many -T ${2:-2048} $W/out $W/f/* > $W/j.json 2> $W/err
 python3 - $W/prof <<'PY'
 import csv, glob, sys
 root = sys.argv[1]

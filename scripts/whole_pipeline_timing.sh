@@ -5,6 +5,7 @@
 # first bytes of $GMX_CORPUS (BASELINE.json configs[0]: GMX_CORPUS=/path/to/enwik8 bash scripts/whole_pipeline_timing.sh 1000000).
 #   bash scripts/whole_pipeline_timing.sh [bytes=100000]
 cd "${GRAFT_REPO_ROOT:-.}"
+. scripts/_paths.sh
 N=${1:-100000}
 W=$(mktemp -d)
 if [ -n "$GMX_CORPUS" ]; then head -c $N "$GMX_CORPUS" > $W/in; else cat SURVEY.md DESIGN.md INTEGRATION.md PAPERS.md SNIPPETS.md 2>/dev/null | head -c $N > $W/in; fi
@@ -13,7 +14,7 @@ for exe in gmix_strict gmix_gpu gmix_chain gmix_batched gmix_chain_batched; do
   IN=$W/in
   mkdir -p $W/$exe && cd $W/$exe
   s=$(date +%s.%N)
-  timeout -k 10 900 $OLDPWD/oracle/_ref/$exe -c $IN $W/$exe/out > /dev/null 2>&1
+  timeout -k 10 900 $(gmxbin $exe) -c $IN $W/$exe/out > /dev/null 2>&1
   rc=$?
   e=$(date +%s.%N)
   cd $OLDPWD
@@ -24,8 +25,8 @@ cmp $W/gmix_strict/out $W/gmix_chain/out && echo "gmix_chain output == gmix_stri
 cmp $W/gmix_strict/out $W/gmix_batched/out && echo "gmix_batched output == gmix_strict output"
 cmp $W/gmix_strict/out $W/gmix_chain_batched/out && echo "gmix_chain_batched output == gmix_strict output"
 # and back: the stock build decodes what the device chain encoded, the device chain what the stock build encoded
-(cd $W/gmix_strict && timeout -k 10 900 $OLDPWD/oracle/_ref/gmix_strict -d $W/gmix_chain/out $W/back_s > /dev/null 2>&1)
+(cd $W/gmix_strict && timeout -k 10 900 $(gmxbin gmix_strict) -d $W/gmix_chain/out $W/back_s > /dev/null 2>&1)
 cmp $W/in $W/back_s && echo "gmix_strict -d (gmix_chain -c (input)) == input"
-(cd $W/gmix_chain && timeout -k 10 900 $OLDPWD/oracle/_ref/gmix_chain -d $W/gmix_strict/out $W/back_c > /dev/null 2>&1)
+(cd $W/gmix_chain && timeout -k 10 900 $(gmxbin gmix_chain) -d $W/gmix_strict/out $W/back_c > /dev/null 2>&1)
 cmp $W/in $W/back_c && echo "gmix_chain -d (gmix_strict -c (input)) == input"
 rm -rf $W

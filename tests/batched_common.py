@@ -1,13 +1,12 @@
 """Shared by tests/test_batched_cpu.py and tests/test_gpu_batched.py: the run-ahead compressor
-(gmix_amd/host/gmx_batched.h inside builds of the reference, oracle/ref_build/Makefile `batched`) beside
+(gmix_amd/host/gmx_batched.h inside builds of the reference, dropin/Makefile) beside
 the stock build of the reference on the same bytes."""
 import json
 import os
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF = os.path.join(ROOT, "oracle", "_ref")
+from dropin_common import ROOT, exe
 
 
 def corpus(n_bytes, offset=0):
@@ -26,15 +25,15 @@ def corpus(n_bytes, offset=0):
     return data[offset:offset + n_bytes]
 
 
-def need(*exes):
-    for exe in exes:
-        assert os.path.exists(os.path.join(REF, exe)), f"oracle/_ref/{exe} missing: make -C oracle/ref_build batched"
+def need(*names):
+    for name in names:
+        assert os.path.exists(exe(name)), f"{exe(name)} missing: make -C oracle/ref_build full && make -C dropin"
 
 
-def gmix(exe, mode, src, dst, cwd, timeout=1100):
-    r = subprocess.run([os.path.join(REF, exe), mode, str(src), str(dst)], cwd=str(cwd), capture_output=True, text=True,
+def gmix(name, mode, src, dst, cwd, timeout=1100):
+    r = subprocess.run([exe(name), mode, str(src), str(dst)], cwd=str(cwd), capture_output=True, text=True,
                        timeout=timeout)
-    assert r.returncode == 0, (exe, r.stdout[-500:], r.stderr[-2000:])
+    assert r.returncode == 0, (name, r.stdout[-500:], r.stderr[-2000:])
 
 
 def compress_pair(stock_exe, batched_exe, data, tmp_path):
@@ -42,8 +41,8 @@ def compress_pair(stock_exe, batched_exe, data, tmp_path):
     src = tmp_path / "input"
     src.write_bytes(data)
     dirs = []
-    for exe in (stock_exe, batched_exe):
-        d = tmp_path / exe
+    for name in (stock_exe, batched_exe):
+        d = tmp_path / name
         d.mkdir()
         dirs.append(d)
     with ThreadPoolExecutor(2) as ex:
@@ -60,44 +59,8 @@ def same_outputs(stock_dir, batched_dir):
     return a
 
 
-def run_many(exe, files, out_dir, chunk_bits, timeout=1100, extra=()):
-    r = subprocess.run([os.path.join(REF, exe), "-T", str(chunk_bits), *extra, str(out_dir)] + [str(f) for f in files],
+def run_many(name, files, out_dir, chunk_bits, timeout=1100, extra=()):
+    r = subprocess.run([exe(name), "-T", str(chunk_bits), *extra, str(out_dir)] + [str(f) for f in files],
                        capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     return json.loads(r.stdout.strip().splitlines()[-1])
-
-
-def train_pair(stock_exe, batched_exe, train, test, tmp_path, checkpoints=None, env=None, timeout=1100):
-    """`gmix -t [checkpoint] train test` (runner_utils::RunTraining, runner-utils.cpp:222-322) of both builds side by
-    side, each in a directory of its own; returns the two directories."""
-    ftrain, ftest = tmp_path / "train", tmp_path / "test"
-    ftrain.write_bytes(train)
-    ftest.write_bytes(test)
-    dirs = []
-    for k, exe in enumerate((stock_exe, batched_exe)):
-        d = tmp_path / f"t{len(list(tmp_path.iterdir()))}_{exe}"
-        d.mkdir()
-        dirs.append(d)
-
-    def one(k):
-        exe, d = (stock_exe, batched_exe)[k], dirs[k]
-        args = [os.path.join(REF, exe), "-t"] + ([str(checkpoints[k])] if checkpoints else []) + [str(ftrain), str(ftest)]
-        r = subprocess.run(args, cwd=str(d), capture_output=True, text=True, timeout=timeout,
-                           env=dict(os.environ, **(env or {})))
-        assert r.returncode == 0 and "training cross entropy" in r.stdout, (exe, r.stdout[-500:], r.stderr[-2000:])
-        return r.stdout[r.stdout.index("training cross entropy"):].splitlines()[0]
-
-    with ThreadPoolExecutor(2) as ex:
-        said = list(ex.map(one, range(2)))
-    assert said[0] == said[1], said
-    return dirs
-
-
-def same_training(stock_dir, batched_dir):
-    """What RunTraining leaves: data/tmp (the coded training file), analysis/training.tsv (train and test cross
-    entropy every other per cent), the two analysis tables, and data/trained_checkpoint."""
-    from dropin_common import same_checkpoint
-    for f in ("data/tmp", "analysis/training.tsv", "analysis/entropy.tsv", "analysis/memory.tsv"):
-        a, b = (stock_dir / f).read_bytes(), (batched_dir / f).read_bytes()
-        assert len(a) > 0 and a == b, f"{f} differs"
-    same_checkpoint(str(stock_dir / "data" / "trained_checkpoint"), str(batched_dir / "data" / "trained_checkpoint"))

@@ -8,14 +8,14 @@ import os
 
 import pytest
 
-from batched_common import REF, compress_pair, corpus, gmix, need, run_many, same_outputs, same_training, train_pair
-from dropin_common import checkpoint_after_batches, compare, run_all, same_checkpoint
+from batched_common import compress_pair, corpus, gmix, need, run_many, same_outputs
+from dropin_common import checkpoint_after_batches, compare, exe as exe_path, run_all, same_checkpoint
 
 
 def _skip_unless(*exes):
     for exe in exes:
-        if not os.path.exists(os.path.join(REF, exe)):
-            pytest.skip(f"oracle/_ref/{exe} not built (needs /root/reference: make -C oracle/ref_build batched)")
+        if not os.path.exists(exe_path(exe)):
+            pytest.skip(f"{exe_path(exe)} not built (needs /root/reference: make -C oracle/ref_build full && make -C dropin)")
 
 
 @pytest.mark.parametrize("exe", ["gmix_batched_shim", "gmix_chain_batched_shim"])
@@ -76,24 +76,21 @@ def test_state_left_behind_equals_the_per_bit_loop(tmp_path, exe, chunk):
     same_checkpoint(os.path.join(stock, "restart"), ck)
 
 
-@pytest.mark.parametrize("exe", ["gmix_batched_shim", "gmix_chain_batched_shim"])
-def test_training_cli_equals_stock(tmp_path, exe):
-    """`gmix -t`: runner_utils::RunTraining answered by gmx::BatchedRunTraining.  24 training bytes in chunks of 40
-    bits, the Predictor synced, copied (Predictor::Copy out of a bank that runs ahead) and the copy scored on 64 test
-    bytes, running ahead as well, eleven times; then Predictor::WriteCheckpoint.  (Small: a Predictor is built per
-    evaluation, and that is seconds here.)"""
+@pytest.mark.parametrize("exe,side_by_side", [("gmix_chain_many_shim", True), ("gmix_many_shim", False)])
+def test_predictors_built_side_by_side_where_no_constructor_draws(tmp_path, exe, side_by_side):
+    """Eight files.  With the LSTM on the device its initial weights -- a constant: every Predictor constructor begins
+    with srand(0xDEADBEEF), predictor.cpp:18 -- come from the pool's one draw (MixerPool::DrawLstmInit) and the
+    Predictors behind the first are constructed at once on their threads; with the host's own LstmModel drawing from
+    rand() (lstm-layer.h:41) constructions stay serial.  Either way every file is the stock build's."""
     _skip_unless("gmix_strict", exe)
-    stock, batched = train_pair("gmix_strict", exe, corpus(24, 100), corpus(64, 3000), tmp_path, env={"GMX_CHUNK_BITS": "40"})
-    same_training(stock, batched)
-
-
-@pytest.mark.slow
-def test_training_with_analysis_rows_equals_stock(tmp_path):
-    """The same with the analysis sampling on (130 training bytes: a row per bit): Predictor::Predict then clears the
-    blackboard's predictions before the models run (predictor.cpp:362-365), so a device-side model that stayed silent
-    at the last bit leaves 0 in the checkpoint, not its last value; the averages of the device-side models go back into
-    ShortTermMemory::entropy."""
-    _skip_unless("gmix_strict", "gmix_chain_batched_shim")
-    stock, batched = train_pair("gmix_strict", "gmix_chain_batched_shim", corpus(130, 100), corpus(16, 3000), tmp_path,
-                                env={"GMX_CHUNK_BITS": "72"})
-    same_training(stock, batched)
+    files = []
+    for k in range(8):
+        f = tmp_path / f"f{k}"
+        f.write_bytes(corpus(150 + 31 * k, 2500 * k))
+        files.append(f)
+    st = run_many(exe, files, tmp_path / "out", 256)
+    assert st["failed"] == 0 and st["parallel_construction"] is side_by_side
+    assert st["total_seconds"] >= st["build_seconds"] + st["wall_seconds"]
+    for k, f in enumerate(files):
+        gmix("gmix_strict", "-c", f, tmp_path / f"ref{k}", tmp_path)
+        assert (tmp_path / f"ref{k}").read_bytes() == (tmp_path / "out" / f"{k}.gmix").read_bytes(), f"file {k}"

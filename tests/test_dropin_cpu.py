@@ -9,7 +9,7 @@ import os
 
 import pytest
 
-from dropin_common import REF, compare, run_all
+from dropin_common import compare, exe as exe_path, run_all
 
 
 @pytest.mark.slow
@@ -22,8 +22,8 @@ def test_reference_tester_with_adapters_equals_stock(tmp_path):
     LSTM bank between its forward and its perceive (include/gmxmix.h)."""
     exes = ("ref_tester_strict", "ref_tester_shim", "ref_tester_chain_shim")
     for exe in exes:
-        if not os.path.exists(os.path.join(REF, exe)):
-            pytest.skip(f"oracle/_ref/{exe} not built (needs /root/reference: make -C oracle/ref_build dropin)")
+        if not os.path.exists(exe_path(exe)):
+            pytest.skip(f"{exe_path(exe)} not built (needs /root/reference: make -C oracle/ref_build full && make -C dropin)")
     stock, mixers, chain = run_all([(exes[0], 300), (exes[1], 300), (exes[2], 300)], 1500, tmp_path)
     compare(stock, mixers)
     compare(stock, chain)

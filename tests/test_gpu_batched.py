@@ -1,6 +1,6 @@
 """The run-ahead compressor on an MI355X (BASELINE.json configs[2] / [3]): the reference's own
 88 feature models and coder on the host cores, running ahead of the 33 mixers, which libgmxmix.so takes in
-double-buffered batches (gmix_amd/host/gmx_batched.h).  Built by oracle/ref_build/Makefile (`batched`) from the
+double-buffered batches (gmix_amd/host/gmx_batched.h).  Built by dropin/Makefile from the
 reference's sources where they lie, with Predictor::AddMixers constructing gmx::GpuMixer and RunCompression calling
 gmx::BatchedCompress: the reference calls the product.  Every file must equal the stock build's."""
 import os
@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import pytest
 
-from batched_common import REF, compress_pair, corpus, gmix, need, run_many, same_outputs, same_training, train_pair
+from batched_common import compress_pair, corpus, gmix, need, run_many, same_outputs
 from dropin_common import checkpoint_after_batches, compare, run_all, run_pair, same_checkpoint
 
 pytestmark = pytest.mark.gpu
@@ -105,23 +105,3 @@ def test_state_left_behind_equals_the_per_bit_loop(gpu, tmp_path):
     (stock,) = run_all([("ref_tester_strict", 0)], 40000, tmp_path)
     for exe, chunk in (("gmix_batched_ckpt", 2048), ("gmix_chain_batched_ckpt", 1000)):
         same_checkpoint(os.path.join(stock, "restart"), checkpoint_after_batches(exe, stock, 40000, chunk, tmp_path))
-
-
-@pytest.mark.parametrize("exe", ["gmix_chain_batched"])   # (the mixers-only build: tests/test_batched_cpu.py, on the shim)
-def test_training_cli_equals_stock_and_resumes_from_its_checkpoint(gpu, tmp_path, exe):
-    """`gmix -t train test` (runner_utils::RunTraining -> gmx::BatchedRunTraining): 20 000 training bytes running
-    ahead, every other per cent the Predictor synced, copied and the copy scored on 1 000 test bytes (running ahead
-    too, in a pool of its own); data/tmp, analysis/training.tsv, both analysis tables, the printed cross entropy and
-    data/trained_checkpoint equal the stock build's.  Then `gmix -t checkpoint train2 test` from that checkpoint
-    (Predictor::ReadCheckpoint into banks that then run ahead; 40 bytes, 19 evaluations: a Predictor is built for each,
-    and that is what a training run's time is made of at these sizes) -- the same again."""
-    need("gmix_strict", exe)
-    a = tmp_path / "first"
-    a.mkdir()
-    stock, batched = train_pair("gmix_strict", exe, corpus(20000, 500), corpus(1000, 90000), a)
-    same_training(stock, batched)
-    b = tmp_path / "second"
-    b.mkdir()
-    cps = [stock / "data" / "trained_checkpoint", batched / "data" / "trained_checkpoint"]
-    stock2, batched2 = train_pair("gmix_strict", exe, corpus(40, 40000), corpus(1000, 90000), b, checkpoints=cps)
-    same_training(stock2, batched2)
