@@ -19,6 +19,7 @@
 
 int main(int argc, char** argv) {
   gmx::BatchedOptions opt;
+  opt.destroy_predictors = false;  // (this process ends with the call: the kernel reclaims faster than 64 destructors)
   unsigned long long limit = 0;
   int a = 1;
   for (; a < argc && argv[a][0] == '-'; ++a) {

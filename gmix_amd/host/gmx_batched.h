@@ -61,6 +61,10 @@ struct BatchedOptions {
   bool progress = true;        // runner-utils.cpp:59-63
   int device = -1;             // BatchedCompressFiles: the pool's device (-1: $GMX_DEVICE, else 0) -- one process per GPU
   bool pin_threads = true;     // BatchedCompressFiles: threads onto the cores of the device's NUMA node
+  bool destroy_predictors = true;  // BatchedCompressFiles / BatchedDecompressFiles: false = leave the Predictors standing when
+                               // the call returns -- for a command-line driver that exits next: 64 destructors give back
+                               // 64 x 2 GB of address space page table by page table (1.8 s for 64 files), the kernel
+                               // reclaims the same in one sweep at exit
   int max_cpus = -1;           // ... onto at most this many of them.  -1: twice what the container's CPU quota is worth
                                // (threads spread over every core of the node spend the quota in a burst and are then
                                // stopped together for the rest of each scheduler period, the device idle meanwhile; a
@@ -408,6 +412,7 @@ inline void RunManyFiles(std::vector<BatchedJob>& jobs, MixerPool& pool, const B
   using clock = std::chrono::steady_clock;
   const clock::time_point tb = clock::now();
   const int S = (int)jobs.size();
+  const bool trace = getenv("GMX_POOL_TRACE") != nullptr;
   pool.Install();  // (draws the LSTM's constant initial weights once, MixerPool::DrawLstmInit)
   std::mutex construct;  // Predictor::Predictor draws the LSTM's weights from rand() after srand() (predictor.cpp:18)
   std::mutex start_mu;
@@ -423,6 +428,7 @@ inline void RunManyFiles(std::vector<BatchedJob>& jobs, MixerPool& pool, const B
     threads.emplace_back([&, s] {
       BatchedJob& job = jobs[s];
       std::unique_ptr<Predictor> p;
+      bool pinned_early = false;
       const bool opened = open(s);
       if (!opened) job.status = -100;
       // The FIRST Predictor is built alone.  If its LSTM turned out to be gmx::GpuLstmModel taking its initial
@@ -444,6 +450,12 @@ inline void RunManyFiles(std::vector<BatchedJob>& jobs, MixerPool& pool, const B
         }
         if (opened) {
           if (pool.parallel_construction()) {
+            // (on its cores first: the constructor touches ~120 MB, which then lie on the device's node, and 64 threads
+            // let loose on every core of the host spend a container's CPU quota in one burst)
+            if (opt.pin_threads && PinThreadToDeviceNode(pool.device(), max_cpus)) {
+              ++pinned;
+              pinned_early = true;
+            }
             p.reset(new Predictor());
           } else {
             std::lock_guard<std::mutex> lk(construct);
@@ -458,11 +470,16 @@ inline void RunManyFiles(std::vector<BatchedJob>& jobs, MixerPool& pool, const B
         else
           start_cv.wait(lk, [&] { return built == S; });
       }
-      if (opt.pin_threads && PinThreadToDeviceNode(pool.device(), max_cpus)) ++pinned;
+      if (!pinned_early && opt.pin_threads && PinThreadToDeviceNode(pool.device(), max_cpus)) ++pinned;
       bool begun = false;
       if (p) {
+        const clock::time_point tb0 = clock::now();
         job.status = hooks.begin(s, p.get());  // every stream is in the pool before the first one records or codes
         begun = job.status == 0;
+        if (trace && (s == 0 || s == S - 1))
+          fprintf(stderr, "[gmx many] stream %d: Predictor stood at %.3f s, joined the pool at %.3f s (begin took %.3f s)\n", s,
+                  std::chrono::duration<double>(tb0 - tb).count(), std::chrono::duration<double>(clock::now() - tb).count(),
+                  std::chrono::duration<double>(clock::now() - tb0).count());
       }
       {  // every Predictor and every bank stands before the first loop starts
         std::unique_lock<std::mutex> lk(start_mu);
@@ -478,7 +495,9 @@ inline void RunManyFiles(std::vector<BatchedJob>& jobs, MixerPool& pool, const B
       ends[s] = clock::now();
       job.seconds = std::chrono::duration<double>(ends[s] - a).count();
       hooks.end(s);
-      if (pool.parallel_construction()) {
+      if (!opt.destroy_predictors) {
+        p.release();
+      } else if (pool.parallel_construction()) {
         p.reset();
       } else {
         std::lock_guard<std::mutex> lk(construct);  // (a Predictor gives back gigabytes: one at a time)

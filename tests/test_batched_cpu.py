@@ -90,7 +90,7 @@ def test_predictors_built_side_by_side_where_no_constructor_draws(tmp_path, exe,
         files.append(f)
     st = run_many(exe, files, tmp_path / "out", 256)
     assert st["failed"] == 0 and st["parallel_construction"] is side_by_side
-    assert st["total_seconds"] >= st["build_seconds"] + st["wall_seconds"]
+    assert st["total_seconds"] >= st["build_seconds"] + st["wall_seconds"] - 2e-3   # (build_seconds is printed to the millisecond)
     for k, f in enumerate(files):
         gmix("gmix_strict", "-c", f, tmp_path / f"ref{k}", tmp_path)
         assert (tmp_path / f"ref{k}").read_bytes() == (tmp_path / "out" / f"{k}.gmix").read_bytes(), f"file {k}"
