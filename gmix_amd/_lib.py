@@ -161,6 +161,16 @@ def lib():
     L.gmx_lockstep_is_persistent.argtypes = [vp]
     L.gmx_lockstep_learn.argtypes = [vp]
     L.gmx_lockstep_learn_predict.argtypes = [vp]
+    L.gmx_chainstep_create.argtypes = [C.POINTER(vp), vp, vp, vp, i32, i32, i32]
+    L.gmx_chainstep_destroy.argtypes = [vp]
+    L.gmx_chainstep_destroy.restype = None
+    L.gmx_chainstep_n_streams.argtypes = [vp]
+    L.gmx_chainstep_step.argtypes = [vp]
+    for name in ("predictions", "active_mask", "contexts", "ind_contexts", "bit_contexts", "ppm", "bits", "what", "p",
+                 "outputs"):
+        f = getattr(L, "gmx_chainstep_" + name)
+        f.argtypes = [vp]
+        f.restype = vp
     for name in ("gmx_group_set_cu_mask", "gmx_indirect_set_cu_mask", "gmx_lstm_set_cu_mask"):
         getattr(L, name).argtypes = [vp, C.POINTER(u32), i32]
     L.gmx_debug_math_probe.argtypes = [i32, vp, vp, u64, i32]
@@ -198,5 +208,9 @@ ABI_SYMBOLS = [
     "gmx_lstm_batch_active", "gmx_lstm_batch_contexts", "gmx_lstm_batch_upload", "gmx_lstm_batch_download",
     "gmx_lstm_batch_wait", "gmx_lstm_run", "gmx_lstm_run_ragged", "gmx_lstm_forward", "gmx_lstm_perceive", "gmx_lstm_feed",
     "gmx_lstm_export", "gmx_lstm_import", "gmx_lstm_copy", "gmx_lstm_memory_usage",
+    "gmx_chainstep_create", "gmx_chainstep_destroy", "gmx_chainstep_n_streams", "gmx_chainstep_predictions",
+    "gmx_chainstep_active_mask", "gmx_chainstep_contexts", "gmx_chainstep_ind_contexts", "gmx_chainstep_bit_contexts",
+    "gmx_chainstep_ppm", "gmx_chainstep_bits", "gmx_chainstep_what", "gmx_chainstep_p", "gmx_chainstep_outputs",
+    "gmx_chainstep_step",
     "gmx_group_set_cu_mask", "gmx_indirect_set_cu_mask", "gmx_lstm_set_cu_mask",
 ]

@@ -315,3 +315,62 @@ class Lockstep:
             self.close()
         except Exception:
             pass
+
+
+STEP_LEARN, STEP_PREDICT = 1, 2
+
+
+class ChainStep:
+    """S decoders in lock step through every device-side model (gmx_chainstep): one hipGraph per coded bit.  `indirect`
+    / `lstm` may be None.  Fill the host views for the streams that take part, set `what`, call step()."""
+
+    def __init__(self, group, indirect=None, lstm=None, lstm_slot=-1, mixer_ctx_col=-1, ind_ctx_col=-1):
+        self.g, self.L = group, group.L
+        h = C.c_void_p()
+        check(self.L.gmx_chainstep_create(C.byref(h), group.h, indirect.h if indirect else None,
+                                          lstm.h if lstm else None, lstm_slot, mixer_ctx_col, ind_ctx_col),
+              "gmx_chainstep_create")
+        self.h = h
+        S, M = group.S, group.topo.n_mixers
+        n_pad = (group.topo.n_inputs + 3) // 4 * 4
+        mw = (group.topo.n_inputs + 31) // 32
+        self.mask_words = mw
+
+        def view(name, dtype, shape):
+            ptr = getattr(self.L, "gmx_chainstep_" + name)(h)
+            if not ptr:
+                return None
+            n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            return np.frombuffer((C.c_char * n).from_address(ptr), dtype=dtype).reshape(shape)
+
+        self.predictions = view("predictions", np.float32, (S, n_pad))
+        self.active_mask = view("active_mask", np.uint32, (S, mw))
+        self.contexts = view("contexts", np.uint32, (S, M))
+        K = indirect.K if indirect else 0
+        self.ind_contexts = view("ind_contexts", np.uint32, (S, K)) if indirect else None
+        self.bit_contexts = view("bit_contexts", np.uint32, (S,)) if indirect else None
+        self.ppm = view("ppm", np.float32, (S, 256)) if lstm else None
+        self.bits = view("bits", np.uint8, (S,))
+        self.what = view("what", np.uint8, (S,))
+        self.p = view("p", np.float32, (S,))
+        self.outputs = view("outputs", np.float32, (S, M))
+
+    def set_active(self, stream, active):
+        """active[N] flags -> the stream's mask words."""
+        padded = np.zeros(self.mask_words * 32, np.uint8)
+        padded[:len(active)] = np.asarray(active) != 0
+        self.active_mask[stream] = np.packbits(padded.reshape(self.mask_words, 32), axis=1, bitorder="little").view(np.uint32).reshape(-1)
+
+    def step(self):
+        check(self.L.gmx_chainstep_step(self.h), "gmx_chainstep_step")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gmx_chainstep_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

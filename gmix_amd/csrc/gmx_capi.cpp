@@ -1484,6 +1484,7 @@ extern "C" int gmx_bank_memory_usage(gmx_group* g, int stream, int mixer, uint64
 
 #include "gmx_indirect.inc"
 #include "gmx_lstm.inc"
+#include "gmx_chainstep.inc"
 
 // ---- test probes (device math against host math; not part of the product surface) --------
 extern "C" int gmx_debug_single_variant(gmx_group* g, int lanes_per_stream) {

@@ -647,3 +647,98 @@ extern "C" hipError_t gmx_launch_indirect_init(uint8_t* banks, uint64_t bank_byt
                      tab_bytes);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------
+// Lock step (gmx_chainstep.inc): ONE bit of every stream per launch, the coded bit of a forward known only a
+// launch later -- S decoders side by side (coder/decoder.cpp:19-39).  One wave per stream, lane = model.  What a
+// stream asks of a step is in what[s]: bit 0 = Indirect::Learn (indirect.cpp:48-69) with bits[s] on the entry the
+// stream's last forward latched, bit 1 = Indirect::Predict (indirect.cpp:28-46) on this step's contexts; 0 = the
+// stream sits the step out.  Between launches a model keeps {table index, entry, "a forward waits for its learn"} in
+// `latch`; logits and slot values are read and written in the bank itself (two logits per model and bit: no LDS copy
+// of the 82 KiB of tables for one bit's work).  Predictions go straight into the mixers' records of the same step.
+__global__ void __launch_bounds__(64)
+gmx_indirect_step_kernel(const GmxIndDev* __restrict__ dv, const GmxIndStepArgs a) {
+  __shared__ uint64_t s_tab[32];
+  __shared__ uint8_t nsn[512], rmn[512];
+  __shared__ uint32_t mwl[8];
+  const int lane = threadIdx.x;
+  const int s = blockIdx.x;
+  const uint32_t what = a.what[s];
+  if (!(what & 3u)) return;
+  const int K = dv->k;
+  if (lane < 32) s_tab[lane] = gmx_exp2f_tab[lane];
+  for (int i = lane; i < 512; i += 64) {
+    nsn[i] = dv->ns_next[i];
+    rmn[i] = dv->rm_next[i];
+  }
+  if (lane < 8) mwl[lane] = 0;
+  __syncthreads();
+  const bool on = lane < K;
+  uint8_t* const bank = a.banks + (uint64_t)s * dv->bank_bytes;
+  uint32_t* const L = a.latch + ((uint64_t)s * 64 + lane) * 4;  // {index, entry, have, -}
+  uint64_t act_a = 0, act_b = 0;
+  float va = 0.f, vb = 0.f;
+  GmxIndModelDev d = dv->m[on ? lane : 0];
+  if (on) {
+    uint16_t* const tab = (uint16_t*)(bank + d.tab_off);
+    float* const nsp = (float*)(bank + dv->pred_off) + (size_t)lane * 512;
+    float* const rmp = nsp + 256;
+    float* const slots = (float*)(bank + dv->slots_off);
+    uint32_t idx = L[0], e = L[1], have = L[2];
+    if ((what & 1u) && have) {
+      const int bit = a.bits[s] ? 1 : 0;
+      const uint32_t ns = e & 255u, rm = e >> 8;
+      const uint32_t sn = ns != 255u ? ns : 0u;  // the uninitialised state learns as state 0
+      const float pa = nsp[sn], qb = rmp[rm];
+      const float na = pa + ((float)bit - gmx_logistic_tab(pa, s_tab)) * d.lr;
+      const float nb = qb + ((float)bit - gmx_logistic_tab(qb, s_tab)) * d.lr;
+      nsp[sn] = na;
+      rmp[rm] = nb;
+      tab[idx] = (uint16_t)((uint32_t)nsn[2 * sn + bit] | ((uint32_t)rmn[2 * rm + bit] << 8));
+      have = 0;
+      __threadfence();  // this lane's own loads below may hit the same entry and logits
+    }
+    if (what & 2u) {
+      const uint32_t ctx = a.ctx[(uint64_t)s * K + lane];
+      idx = ((ctx << 8) + a.bc[s]) % d.size;  // indirect.cpp:31-32, 32-bit wrap
+      e = tab[idx];
+      const uint32_t ns = e & 255u, rm = e >> 8;
+      const bool seen_a = ns != 255u, seen_b = rm != 0u;  // never-seen states leave the slot alone
+      va = slots[2 * lane];
+      vb = slots[2 * lane + 1];
+      const float qa = seen_a ? nsp[ns] : 0.f, qb = seen_b ? rmp[rm] : 0.f;
+      if (seen_a) slots[2 * lane] = va = qa;
+      if (seen_b) slots[2 * lane + 1] = vb = qb;
+      if (seen_a && qa != 0.f) atomicOr(&mwl[d.slot_a >> 5], 1u << (d.slot_a & 31));  // a zero logit is stored, not active
+      if (seen_b && qb != 0.f) atomicOr(&mwl[d.slot_b >> 5], 1u << (d.slot_b & 31));
+      act_a = seen_a && qa != 0.f;
+      act_b = seen_b && qb != 0.f;
+      have = 1;
+      if (a.mx_pred) {
+        float* const mp = a.mx_pred + (uint64_t)s * a.mx_n_pad;
+        mp[d.slot_a] = va;
+        mp[d.slot_b] = vb;
+      }
+      if (a.pred_out) {
+        a.pred_out[((uint64_t)s * K + lane) * 2] = va;
+        a.pred_out[((uint64_t)s * K + lane) * 2 + 1] = vb;
+        a.act_out[((uint64_t)s * K + lane) * 2] = (uint8_t)act_a;
+        a.act_out[((uint64_t)s * K + lane) * 2 + 1] = (uint8_t)act_b;
+      }
+    }
+    L[0] = idx;
+    L[1] = e;
+    L[2] = have;
+  }
+  __syncthreads();
+  // the mask words of the mixers' record: the host left the models' bits clear
+  if ((what & 2u) && a.mx_mask && lane < a.mx_mask_words && lane < 8)
+    a.mx_mask[(uint64_t)s * a.mx_mask_words + lane] |= mwl[lane];
+}
+
+extern "C" hipError_t gmx_launch_indirect_step(const GmxIndDev* dv, const GmxIndStepArgs* args, int n_streams,
+                                               hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gmx_indirect_step_kernel, dim3(n_streams), dim3(64), 0, stream, dv, *args);
+  return hipGetLastError();
+}

@@ -228,6 +228,21 @@ struct GmxIndRunArgs {
   int32_t mx_n_pad, mx_mask_words;
 };
 
+// One bit of every stream, the coded bit of a forward known a launch later (gmx_indirect_step_kernel, gmx_chainstep.inc)
+struct GmxIndStepArgs {
+  uint8_t* banks;
+  const uint32_t* ctx;     // [S][k]  the models' contexts of this step's Predict
+  const uint32_t* bc;      // [S]     bit_context
+  const uint8_t* bits;     // [S]     the coded bit of each stream's previous forward
+  const uint8_t* what;     // [S]     bit 0: learn, bit 1: predict; 0: the stream sits out
+  uint32_t* latch;         // [S][64][4] per model: table index, entry, "a forward waits for its learn"
+  float* mx_pred;          // [S][mx_n_pad] the mixers' records of the same step, or null
+  uint32_t* mx_mask;       // [S][mx_mask_words]
+  int32_t mx_n_pad, mx_mask_words;
+  float* pred_out;         // [S][2k] or null (tests)
+  uint8_t* act_out;        // [S][2k]
+};
+
 // ---- LSTM byte model (models/lstm*.cpp) -----------------------
 // The reference builds Lstm(256, 256, 50, 1, 100, 0.03, 10) (lstm-model.cpp:7).  One stream's
 // state, in floats (u32 where noted), every [cell] vector padded to 64:
@@ -298,6 +313,19 @@ struct GmxLstmRunArgs {
   struct GmxLstmMbCmd* mc;
   struct GmxLstmMbReply* mb;
   uint64_t idle_ticks;
+};
+
+// The LSTM's prediction of ONE bit of every stream in lock step (gmx_lstm_bitstep_kernel, gmx_chainstep.inc):
+// LstmModel::Predict's range walk (lstm-model.cpp:34-48) with the byte's bits arriving one step apart.
+struct GmxLstmBitArgs {
+  float* banks;
+  const uint8_t* bits;     // [S] the coded bit of each stream's previous step
+  const uint8_t* what;     // [S] bit 1: predict this step; bit 2: the step opens a byte (Lstm::Predict has just run)
+  float* mx_pred;          // [S][mx_n_pad]
+  uint32_t* mx_mask;       // [S][mx_mask_words]
+  uint32_t* mx_ctx;        // [S][mx_m]
+  uint32_t* ind_ctx;       // [S][ind_k] or null
+  int32_t mx_n_pad, mx_mask_words, mx_m, slot, mixer_ctx_col, ind_k, ind_ctx_col;
 };
 
 // Mailbox of a per-byte session of the LSTM byte model: the protocol of the mixers' and the Indirect models'

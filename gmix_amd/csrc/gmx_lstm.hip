@@ -850,3 +850,68 @@ extern "C" hipError_t gmx_launch_lstm_scatter(const GmxLstmScatterArgs* args, in
   hipLaunchKernelGGL(gmx_lstm_scatter_kernel, dim3(blocks, n_streams), dim3(256), 0, stream, *args);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------
+// Lock step (gmx_chainstep.inc): the LSTM's prediction of ONE bit of every stream per launch -- LstmModel::Predict's
+// walk down the byte distribution (lstm-model.cpp:34-48) with the byte's bits arriving a launch apart, as S decoders
+// side by side produce them (coder/decoder.cpp:19-39).  The distribution is the bank's (Lstm::Predict ran in the
+// launch before a byte's first bit: what[s] bit 2), the range [bot, top] lives in the bank's scalars between
+// launches (scal[8], scal[9]; mid_ follows from them), the prediction goes where ShortTermMemory::SetPrediction
+// (short-term-memory.cpp:187-191) puts it -- slot `slot` of the mixers' record of the same step, with its active bit --
+// and lstm_prediction_context (lstm-model.cpp:25-33) into the gate-context / Indirect-context columns that read it.
+// One wave per stream; the two ordered sums (std::accumulate from the first element up) are one lane's.
+__global__ void __launch_bounds__(64)
+gmx_lstm_bitstep_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmBitArgs a) {
+  __shared__ float pr[GMX_L_NO];
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const uint32_t what = a.what[s];
+  if (!(what & 2u)) return;
+  float* const B = a.banks + (uint64_t)s * dvp->bank_floats;
+  uint32_t* const scal = (uint32_t*)(B + dvp->scal);
+  const float4 q = ((const float4*)(B + dvp->probs))[lane];
+  ((float4*)pr)[lane] = q;
+  __syncthreads();
+  if (lane != 0) return;
+  int top, bot;
+  if (what & 4u) {
+    top = 255;
+    bot = 0;
+  } else {
+    top = (int)scal[8];
+    bot = (int)scal[9];
+    const int mid_before = bot + ((top - bot) / 2);
+    if (a.bits[s])
+      bot = mid_before + 1;
+    else
+      top = mid_before;
+  }
+  const int mid = bot + ((top - bot) / 2);
+  float num = 0.0f;
+  for (int i = mid + 1; i <= top; ++i) num += pr[i];
+  float denom = num;
+  for (int i = bot; i <= mid; ++i) denom += pr[i];
+  float prediction = __uint_as_float(scal[5]);
+  bool active = false;
+  if (denom != 0.0f) {  // (a silent bit leaves the slot as it was)
+    const float p = num / denom;
+    prediction = gmx_logit(p);
+    active = p != 0.5f;
+    scal[5] = __float_as_uint(prediction);
+  }
+  scal[8] = (uint32_t)top;
+  scal[9] = (uint32_t)bot;
+  a.mx_pred[(uint64_t)s * a.mx_n_pad + a.slot] = prediction;
+  uint32_t* const w = a.mx_mask + (uint64_t)s * a.mx_mask_words + (a.slot >> 5);
+  const uint32_t m = 1u << (a.slot & 31);
+  *w = active ? (*w | m) : (*w & ~m);
+  const uint32_t c = scal[4];
+  if (a.mixer_ctx_col >= 0) a.mx_ctx[(uint64_t)s * a.mx_m + a.mixer_ctx_col] = c;
+  if (a.ind_ctx && a.ind_ctx_col >= 0) a.ind_ctx[(uint64_t)s * a.ind_k + a.ind_ctx_col] = c;
+}
+
+extern "C" hipError_t gmx_launch_lstm_bitstep(const GmxLstmDev* dv, const GmxLstmBitArgs* args, int n_streams,
+                                              hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gmx_lstm_bitstep_kernel, dim3(n_streams), dim3(64), 0, stream, dv, *args);
+  return hipGetLastError();
+}

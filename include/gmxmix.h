@@ -407,6 +407,42 @@ int gmx_lstm_import(gmx_lstm* l, int stream, const void* long_buf, size_t long_b
 int gmx_lstm_copy(gmx_lstm* dst, int dst_stream, gmx_lstm* src, int src_stream);
 int gmx_lstm_memory_usage(gmx_lstm* l, uint64_t* bytes);
 
+/* ==== Lock step through the whole device chain: S decoders, one device step per coded bit ======
+ * The reference's Decoder (coder/decoder.cpp:19-39) learns each bit from Predict's own result, so S files being
+ * restored on one GPU advance together, a bit per step (gmx_lockstep_* above does this for the mixers alone).  A
+ * gmx_chainstep steps the LSTM byte model and the Indirect models with the mixers -- `ib` and `l` may be NULL: the
+ * caller's records then carry those models' predictions like any other -- so that, as in the batched chain
+ * (gmx_lstm_feed, gmx_indirect_run's `into`), the LSTM's prediction (slot lstm_slot of the mixers' inputs, its active
+ * bit, lstm_prediction_context in gate-context column mixer_ctx_col and Indirect-context column ind_ctx_col; < 0: none)
+ * and the Indirect models' 2 x K predictions never leave the device.
+ * Per step the caller fills, for every stream s that takes part, what[s] and the host arrays the step reads:
+ *   GMX_STEP_LEARN    bits[s] = the bit the stream decoded from the last step's p[s]: Predictor::Learn -- Mixer::Learn
+ *                     x M, Indirect::Learn x K, and Lstm::Perceive when the bit completes a byte
+ *   GMX_STEP_PREDICT  predictions[s][n_pad] (the blackboard; the device-side models' slots are overwritten), active_mask
+ *                     [s][mask_words] (their bits left clear), contexts[s][M], ind_contexts[s][K], bit_contexts[s], and
+ *                     -- when the bit opens a byte -- ppm[s][256] (ShortTermMemory::ppm_predictions): Predictor::Predict
+ * and calls gmx_chainstep_step, which returns with p[s] (and outputs[s][M]) of the streams that predicted.  A stream
+ * whose what[s] is 0 sits the step out (its file has ended); streams start at a byte boundary.  One hipGraph per step
+ * (two uploads, the kernels, one download); same floats as every other surface.  Destroy before the banks. */
+#define GMX_STEP_LEARN 1u
+#define GMX_STEP_PREDICT 2u
+typedef struct gmx_chainstep gmx_chainstep;
+int gmx_chainstep_create(gmx_chainstep** out, gmx_group* g, gmx_indirect* ib /* nullable */, gmx_lstm* l /* nullable */,
+                         int lstm_slot, int mixer_ctx_col, int ind_ctx_col);
+void gmx_chainstep_destroy(gmx_chainstep* cs);
+int gmx_chainstep_n_streams(const gmx_chainstep* cs);
+float* gmx_chainstep_predictions(gmx_chainstep* cs);     /* pinned host [S][n_pad] */
+uint32_t* gmx_chainstep_active_mask(gmx_chainstep* cs);  /* [S][mask_words] */
+uint32_t* gmx_chainstep_contexts(gmx_chainstep* cs);     /* [S][M] */
+uint32_t* gmx_chainstep_ind_contexts(gmx_chainstep* cs); /* [S][K]; NULL without Indirect models */
+uint32_t* gmx_chainstep_bit_contexts(gmx_chainstep* cs); /* [S] */
+float* gmx_chainstep_ppm(gmx_chainstep* cs);             /* [S][256]; NULL without an LSTM */
+uint8_t* gmx_chainstep_bits(gmx_chainstep* cs);          /* [S] */
+uint8_t* gmx_chainstep_what(gmx_chainstep* cs);          /* [S] GMX_STEP_* */
+const float* gmx_chainstep_p(gmx_chainstep* cs);         /* [S] */
+const float* gmx_chainstep_outputs(gmx_chainstep* cs);   /* [S][M] */
+int gmx_chainstep_step(gmx_chainstep* cs);
+
 /* ==== Compute-unit shares ======================================================================
  * A bank's kernels normally spread over the whole chip.  Kernels of DIFFERENT banks that cannot share
  * a SIMD -- a mixer wave of the stock shape owns all 512 registers of its SIMD, an LSTM workgroup
