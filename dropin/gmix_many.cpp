@@ -3,9 +3,11 @@
 // Linked by dropin/Makefile against the reference's own translation units (feature models, coder,
 // runner-utils) with Predictor::AddMixers constructing gmx::GpuMixer -- the reference calls the product.
 //
-// usage: gmix_many [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--device d] <out dir> <input file>...
+// usage: gmix_many [-d] [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--device d] <out dir> <input file>...
 //   each input is compressed to <out dir>/<index>.gmix exactly as `gmix -c` would (runner-utils.cpp:88-121);
 //   -n limits every input to its first n bytes (written to <out dir>/<index>.in first).
+//   -d: each input is a file `gmix -c` wrote and is restored to <out dir>/<index>.out as `gmix -d` would
+//   (runner-utils.cpp:123-156), all files together through gmx::BatchedDecompressFiles (Decoders in lock step).
 //   One JSON line on stdout: per-file sizes and times, the wall time of the compression phase, bits, launches.
 #include <cstdio>
 #include <cstdlib>
@@ -21,9 +23,12 @@ int main(int argc, char** argv) {
   gmx::BatchedOptions opt;
   opt.destroy_predictors = false;  // (this process ends with the call: the kernel reclaims faster than 64 destructors)
   unsigned long long limit = 0;
+  bool decode = false;
   int a = 1;
   for (; a < argc && argv[a][0] == '-'; ++a) {
-    if (!strcmp(argv[a], "-T") && a + 1 < argc)
+    if (!strcmp(argv[a], "-d"))
+      decode = true;
+    else if (!strcmp(argv[a], "-T") && a + 1 < argc)
       opt.chunk_bits = strtoull(argv[++a], 0, 0);
     else if (!strcmp(argv[a], "-n") && a + 1 < argc)
       limit = strtoull(argv[++a], 0, 0);
@@ -37,7 +42,7 @@ int main(int argc, char** argv) {
       break;
   }
   if (argc - a < 2) {
-    fprintf(stderr, "usage: %s [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--device d] <out dir> <input file>...\n", argv[0]);
+    fprintf(stderr, "usage: %s [-d] [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--device d] <out dir> <input file>...\n", argv[0]);
     return 2;
   }
   const std::string out_dir = argv[a++];
@@ -54,23 +59,23 @@ int main(int argc, char** argv) {
       j.input_path = out_dir + "/" + std::to_string(k) + ".in";
       std::ofstream(j.input_path, std::ios::binary).write(head.data(), head.size());
     }
-    j.output_path = out_dir + "/" + std::to_string(k) + ".gmix";
+    j.output_path = out_dir + "/" + std::to_string(k) + (decode ? ".out" : ".gmix");
     jobs.push_back(j);
   }
   gmx::BatchedStats st;
-  const int failed = gmx::BatchedCompressFiles(jobs, opt, &st);
+  const int failed = decode ? gmx::BatchedDecompressFiles(jobs, opt, &st) : gmx::BatchedCompressFiles(jobs, opt, &st);
   unsigned long long in_bytes = 0, out_bytes = 0;
-  for (auto& j : jobs) {
-    in_bytes += j.input_bytes;
-    out_bytes += j.output_bytes;
+  for (auto& j : jobs) {  // (in: the plain side, out: the coded side, whichever way the files went)
+    in_bytes += decode ? j.output_bytes : j.input_bytes;
+    out_bytes += decode ? j.input_bytes : j.output_bytes;
   }
   // "cold": the whole call -- pool, Predictors, device banks, coding, teardown -- as runner_utils::RunCompression
   // (runner-utils.cpp:88-121) builds its Predictor inside; "bits_per_second" is the coding loops alone.
-  printf("{\"files\": %zu, \"failed\": %d, \"chunk_bits\": %llu, \"total_seconds\": %.6f, \"wall_seconds\": %.6f, "
+  printf("{\"mode\": \"%s\", \"files\": %zu, \"failed\": %d, \"chunk_bits\": %llu, \"total_seconds\": %.6f, \"wall_seconds\": %.6f, "
          "\"build_seconds\": %.3f, \"first_predictor_seconds\": %.3f, \"teardown_seconds\": %.3f, "
          "\"parallel_construction\": %s, \"launches\": %llu, \"device_bits\": %llu, \"pinned_threads\": %d, "
          "\"pinned_cpus\": %d, \"submit_seconds\": %.4f, \"wait_seconds\": %.4f, \"jobs\": [",
-         jobs.size(), failed, (unsigned long long)opt.chunk_bits, st.total_seconds, st.wall_seconds, st.build_seconds,
+         decode ? "decompress" : "compress", jobs.size(), failed, (unsigned long long)opt.chunk_bits, st.total_seconds, st.wall_seconds, st.build_seconds,
          st.first_predictor_seconds, st.teardown_seconds, st.parallel_construction ? "true" : "false",
          (unsigned long long)st.launches, (unsigned long long)st.bits, st.pinned_threads, st.pinned_cpus, st.submit_seconds,
          st.wait_seconds);

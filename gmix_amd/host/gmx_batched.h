@@ -38,6 +38,7 @@
 #define GMX_BATCHED_H_
 
 #include <sched.h>
+#include <sys/mman.h>
 
 #include <chrono>
 #include <climits>
@@ -48,6 +49,7 @@
 #include <iomanip>
 #include <thread>
 
+#include "coder/decoder.h"          // the reference's
 #include "coder/encoder.h"          // the reference's
 #include "gmx_model_adapter.h"
 #include "predictor.h"              // the reference's
@@ -566,6 +568,294 @@ inline int BatchedCompressFiles(std::vector<BatchedJob>& jobs, const BatchedOpti
   int failed = 0;
   for (auto& j : jobs) failed += j.status != 0;
   if (pool.status() != 0) fprintf(stderr, "gmx::BatchedCompressFiles: %s\n", pool.error().c_str());
+  return failed;
+}
+
+// ---- many files restored side by side: S of the reference's Decoders in lock step ------------------------------
+// Decoder::Decode (coder/decoder.cpp:19-39) calls Predictor::Predict, takes the bit from the code stream and the
+// probability, then Perceive and Learn: the bit is only known when Predict has returned, so nothing runs ahead.  But S
+// files can be restored TOGETHER: every Decoder runs on a fibre of its own; its Predict records the device-side models'
+// inputs (gmx_model_adapter.h, lock-step mode) and hands the thread to the next fibre; when every fibre of every
+// worker thread waits, ONE device step (gmx_chainstep: LSTM, Indirect models and mixers of all S streams, one hipGraph)
+// produces all S probabilities, and the fibres go on -- Perceive, Learn, the next Predict.  The Decoders, the Predictors
+// and the feature models on the host are the reference's own, unmodified; a stream whose file has ended sits the
+// remaining steps out.
+extern "C" void gmx_fiber_switch(void** save_sp, void* load_sp);
+#if defined(__x86_64__)
+// (callee-saved registers of the System V ABI on the old stack, stack pointers swapped, the same registers off the
+// new one; a fresh fibre's stack holds six zeros and the address of its entry function)
+asm(".text\n"
+    ".weak gmx_fiber_switch\n"
+    ".type gmx_fiber_switch,@function\n"
+    "gmx_fiber_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n"
+    ".size gmx_fiber_switch,.-gmx_fiber_switch\n");
+#else
+#error "gmx::LockstepRunner's fibres are written for x86-64 (the reference's hosts)"
+#endif
+
+class LockstepRunner {
+ public:
+  struct Fiber {
+    std::function<void()> fn;
+    void* sp = nullptr;
+    void* sched_sp = nullptr;  // where the worker that runs it waits
+    char* stack = nullptr;
+    size_t stack_bytes = 0;
+    bool done = false;
+    int slot = -1;             // its stream of the pool
+  };
+  // n_workers threads; fibre i runs on worker i % n_workers
+  LockstepRunner(MixerPool* pool, int n_workers) : pool_(pool), W_(n_workers < 1 ? 1 : n_workers), workers_(W_) {}
+  ~LockstepRunner() {
+    for (auto& f : fibers_)
+      if (f->stack) munmap(f->stack, f->stack_bytes);
+  }
+  // Before Run: a body for fibre `index` (bodies run in index order within a worker).
+  void Add(int index, std::function<void()> fn) {
+    if ((int)fibers_.size() <= index) fibers_.resize(index + 1);
+    std::unique_ptr<Fiber> f(new Fiber());
+    f->fn = std::move(fn);
+    f->stack_bytes = kStackBytes;
+    void* m = mmap(nullptr, kStackBytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
+    if (m == MAP_FAILED) {
+      fprintf(stderr, "gmx::LockstepRunner: no memory for a fibre's stack\n");
+      abort();
+    }
+    mprotect(m, 4096, PROT_NONE);  // a guard page at the far end
+    f->stack = (char*)m;
+    uintptr_t top = ((uintptr_t)m + kStackBytes) & ~(uintptr_t)15;
+    void** sp = (void**)top;
+    *--sp = nullptr;               // (what the entry function would return to: it never does)
+    *--sp = (void*)&Entry;
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;
+    f->sp = sp;
+    fibers_[index] = std::move(f);
+  }
+  // The calling thread's fibre waits for the next step (MixerPool::SetLockstepYield).
+  static void Yield() {
+    Fiber* f = Current();
+    gmx_fiber_switch(&f->sp, f->sched_sp);
+  }
+  // `setup(worker)` on every worker thread first (pinning, Predictor construction), then the fibres until all have
+  // ended; `step()` by one thread whenever every live fibre waits.  Returns the steps taken.
+  uint64_t Run(const std::function<void(int)>& setup, const std::function<int()>& step) {
+    std::vector<std::thread> threads;
+    live_.store((int)fibers_.size());
+    for (int w = 0; w < W_; ++w) threads.emplace_back([&, w] { Work(w, setup, step); });
+    for (auto& t : threads) t.join();
+    return steps_;
+  }
+
+ private:
+  static constexpr size_t kStackBytes = 1u << 20;
+  static Fiber*& Current() {
+    static thread_local Fiber* f = nullptr;
+    return f;
+  }
+  static void Entry() {
+    Fiber* f = Current();
+    f->fn();
+    f->done = true;
+    gmx_fiber_switch(&f->sp, f->sched_sp);
+    abort();  // (a finished fibre is never resumed)
+  }
+  void Resume(Fiber* f) {
+    Current() = f;
+    gmx_fiber_switch(&f->sched_sp, f->sp);
+    Current() = nullptr;
+  }
+  // every worker arrives; the last one runs fn; all leave together
+  template <class F>
+  void Barrier(F fn) {
+    const unsigned gen = gen_.load(std::memory_order_acquire);
+    if (arrived_.fetch_add(1, std::memory_order_acq_rel) + 1 == W_) {
+      fn();
+      arrived_.store(0, std::memory_order_relaxed);
+      gen_.store(gen + 1, std::memory_order_release);
+    } else {
+      unsigned spins = 0;
+      while (gen_.load(std::memory_order_acquire) == gen) {
+        if (++spins < 4096) {
+          __builtin_ia32_pause();
+        } else {
+          std::this_thread::yield();
+        }
+      }
+    }
+  }
+  void Work(int w, const std::function<void(int)>& setup, const std::function<int()>& step) {
+    setup(w);
+    Barrier([] {});
+    std::vector<Fiber*> mine;
+    for (size_t i = w; i < fibers_.size(); i += W_)
+      if (fibers_[i]) mine.push_back(fibers_[i].get());
+    for (;;) {
+      for (Fiber* f : mine) {
+        if (f->done) continue;
+        Resume(f);
+        if (f->done) live_.fetch_sub(1);
+      }
+      Barrier([&] {
+        // every live fibre of every worker waits for its step (or has just ended)
+        if (failed_.load() == 0 && step() != 0) failed_.store(1);
+        ++steps_;
+        finished_.store(live_.load() == 0 || failed_.load() != 0);
+      });
+      if (finished_.load()) break;
+    }
+  }
+
+  MixerPool* pool_;
+  const int W_;
+  struct Worker {};
+  std::vector<Worker> workers_;
+  std::vector<std::unique_ptr<Fiber>> fibers_;
+  std::atomic<int> arrived_{0}, live_{0}, failed_{0};
+  std::atomic<unsigned> gen_{0};
+  std::atomic<bool> finished_{false};
+  uint64_t steps_ = 0;
+};
+
+// runner_utils::Decompress (runner-utils.cpp:69-86) for a Predictor whose device-side models step in lock step with
+// the other Predictors of its pool: the reference's Decoder, bit by bit.  Returns 0 or a gmx_status.
+inline int LockstepDecompress(unsigned long long output_length, std::ifstream* is, std::ofstream* os, Predictor* p) {
+  std::shared_ptr<GpuMixerBank> bank = GpuMixerBank::Of(p, sizeof(Predictor));
+  if (!bank) {
+    fprintf(stderr, "gmx::LockstepDecompress: this Predictor's mixers are not gmx::GpuMixer\n");
+    return GMX_ERR_INVALID;
+  }
+  int rc = bank->BeginLockstep();
+  if (rc) return rc;
+  {
+    Decoder d(is, p);
+    for (unsigned long long pos = 0; pos < output_length && bank->status() == 0; ++pos) {
+      int byte = 1;
+      while (byte < 256) byte += byte + d.Decode();
+      os->put(byte);
+    }
+  }
+  rc = bank->EndLockstep();
+  return rc ? rc : bank->status();
+}
+
+// runner_utils::RunDecompression (runner-utils.cpp:123-156) for every job at once: a Predictor and a Decoder per file,
+// all device-side models of all of them one device step per coded bit.  opt.max_cpus worker threads (default: the
+// container's CPU quota, else the hardware's threads, at most one per file) carry the files' fibres.  Returns the
+// number of jobs that failed.
+inline int BatchedDecompressFiles(std::vector<BatchedJob>& jobs, const BatchedOptions& opt_in = BatchedOptions(),
+                                  BatchedStats* stats = nullptr) {
+  using clock = std::chrono::steady_clock;
+  const clock::time_point tb = clock::now();
+  BatchedOptions opt = opt_in;
+  const int S = (int)jobs.size();
+  if (S == 0) return 0;
+  int W = opt.max_cpus > 0 ? opt.max_cpus : QuotaCpus();
+  if (W <= 0) W = (int)std::thread::hardware_concurrency();
+  if (W <= 0) W = 1;
+  if (W > S) W = S;
+  MixerPool pool(S, opt.device);
+  pool.Install();
+  std::vector<std::ifstream> in(S);
+  std::vector<std::ofstream> out(S);
+  std::vector<std::unique_ptr<Predictor>> preds(S);
+  std::mutex construct, first_mu;
+  std::condition_variable first_cv;
+  bool first_built = false;
+  std::atomic<int> pinned{0};
+  clock::time_point t_first = tb, t0 = tb, t1 = tb;
+  LockstepRunner runner(&pool, W);
+  pool.SetLockstepYield([](int) { LockstepRunner::Yield(); });
+  std::vector<char> worker_pinned(W, 0);
+  auto pin = [&](int w) {
+    if (worker_pinned[w]) return;
+    worker_pinned[w] = 1;
+    if (opt.pin_threads && PinThreadToDeviceNode(pool.device(), W)) ++pinned;
+  };
+  for (int s = 0; s < S; ++s) {
+    runner.Add(s, [&, s] {
+      BatchedJob& job = jobs[s];
+      pin(s % W);  // (where constructors draw from rand() the threads are only pinned now, with every Predictor standing)
+      if (job.status || !preds[s]) return;
+      const clock::time_point a = clock::now();
+      job.status = LockstepDecompress(job.output_bytes, &in[s], &out[s], preds[s].get());
+      job.seconds = std::chrono::duration<double>(clock::now() - a).count();
+      out[s].close();
+    });
+  }
+  auto setup = [&](int w) {
+    for (int s = w; s < S; s += W) {
+      BatchedJob& job = jobs[s];
+      in[s].open(job.input_path, std::ios::in | std::ios::binary);
+      bool ok = in[s].is_open();
+      if (ok) {
+        in[s].seekg(0, std::ios::end);
+        job.input_bytes = in[s].tellg();
+        in[s].seekg(0, std::ios::beg);
+        runner_utils::ReadHeader(&in[s], &job.output_bytes);
+        out[s].open(job.output_path, std::ios::out | std::ios::binary);
+        ok = out[s].is_open();
+      }
+      if (!ok) job.status = -100;
+      // (construction as in RunManyFiles: the first Predictor alone, the others side by side when no constructor draws)
+      if (s == 0) {
+        if (ok) preds[0].reset(new Predictor());
+        std::lock_guard<std::mutex> lk(first_mu);
+        first_built = true;
+        t_first = clock::now();
+        first_cv.notify_all();
+        continue;
+      }
+      {
+        std::unique_lock<std::mutex> lk(first_mu);
+        first_cv.wait(lk, [&] { return first_built; });
+      }
+      if (!ok) continue;
+      if (pool.parallel_construction()) {
+        pin(w);
+        preds[s].reset(new Predictor());
+      } else {
+        std::lock_guard<std::mutex> lk(construct);
+        preds[s].reset(new Predictor());
+      }
+    }
+  };
+  bool started = false;
+  const uint64_t steps = runner.Run(setup, [&] {
+    if (!started) {
+      started = true;
+      t0 = clock::now();  // (the first step: every fibre has built nothing more than its first record)
+    }
+    return pool.StepAll();
+  });
+  t1 = clock::now();
+  pool.SetLockstepYield(nullptr);
+  if (opt.destroy_predictors) {
+    preds.clear();
+  } else {
+    for (auto& p : preds) p.release();
+  }
+  pool.Uninstall();
+  int failed = 0;
+  for (auto& j : jobs) failed += j.status != 0;
+  if (pool.status() != 0) fprintf(stderr, "gmx::BatchedDecompressFiles: %s\n", pool.error().c_str());
+  if (stats) {
+    const clock::time_point tz = clock::now();
+    stats->total_seconds = std::chrono::duration<double>(tz - tb).count();
+    stats->wall_seconds = std::chrono::duration<double>(t1 - t0).count();
+    stats->build_seconds = std::chrono::duration<double>(t0 - tb).count();
+    stats->first_predictor_seconds = std::chrono::duration<double>(t_first - tb).count();
+    stats->teardown_seconds = std::chrono::duration<double>(tz - t1).count();
+    stats->parallel_construction = pool.parallel_construction();
+    stats->launches = steps;
+    for (auto& j : jobs) stats->bits += 8ull * j.output_bytes;
+    stats->pinned_threads = pinned.load();
+    stats->pinned_cpus = W;
+  }
   return failed;
 }
 

@@ -45,6 +45,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <numeric>
@@ -144,6 +145,7 @@ class MixerPool {
       if (iring_[k]) gmx_ind_batch_destroy(iring_[k]);
       if (lring_[k]) gmx_lstm_batch_destroy(lring_[k]);
     }
+    if (cs_) gmx_chainstep_destroy(cs_);
     if (group_) gmx_group_destroy(group_);
     if (ind_) gmx_indirect_destroy(ind_);
     if (lstm_) gmx_lstm_destroy(lstm_);
@@ -221,6 +223,30 @@ class MixerPool {
 
   enum Parts { kMixers = 1, kIndirect = 2, kLstm = 4 };
 
+  // ---- lock step (decoding).  A decoder learns each bit from Predict's own result (coder/decoder.cpp:19-39), so
+  // the Predictors of a pool that decode advance together, one device step (gmx_chainstep) per coded bit: every
+  // stream's Predict records its inputs and WAITS (`yield`: the caller's scheduler runs the other streams meanwhile --
+  // gmx::LockstepRunner puts each decoder on a fibre); when every stream has got there the scheduler calls StepAll and
+  // resumes them with their probabilities.  Without a scheduler (one Predictor, one thread) a stream's Predict runs
+  // the step itself.
+  void SetLockstepYield(std::function<void(int)> yield) { yield_ = std::move(yield); }
+  // One step for every stream that asked for one since the last; mu_ NOT held; only ever one thread at a time.
+  int StepAll() {
+    if (!cs_ || status_.load()) return status_.load();
+    int rc;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      rc = gmx_chainstep_step(cs_);
+      if (rc) Fail("gmx_chainstep_step", rc);
+    }
+    if (rc == GMX_OK) {
+      memset(ls_what_, 0, (size_t)S_);
+      ++round_;
+    }
+    return rc;
+  }
+  int lockstep_streams() const { return ls_participants_; }
+
  private:
   friend class GpuMixerBank;
   friend class GpuIndirectBank;
@@ -242,6 +268,7 @@ class MixerPool {
     uint8_t* ibits = nullptr;
     float* ppm = nullptr;
     uint8_t* bytes = nullptr;
+    bool ls = false;  // lock step: Predict records into the chainstep's arrays and waits for the step
   };
 
   // The pool and stream of the Predictor that owns `ltm`: the installed pool, else a pool of its own (shared by
@@ -575,9 +602,53 @@ class MixerPool {
     if (participants_ > 0 && arrived_ >= participants_ && status_.load() == 0) Lead();
   }
 
+  // ---- lock step ----
+  int JoinLockstep(int slot, int parts, int lstm_slot, int mixer_ctx_col, int ind_ctx_col) {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (status_.load()) return status_.load();
+    if (ring_[0]) return GMX_ERR_STATE;  // (a pool runs ahead or steps, not both)
+    if (!cs_) {
+      int rc = gmx_chainstep_create(&cs_, group_, (parts & kIndirect) ? ind_ : nullptr, (parts & kLstm) ? lstm_ : nullptr,
+                                    lstm_slot, mixer_ctx_col, ind_ctx_col);
+      if (rc) return Fail("gmx_chainstep_create", rc);
+      parts_ = parts;
+      lstm_slot_ = lstm_slot;
+      mixer_ctx_col_ = mixer_ctx_col;
+      ind_ctx_col_ = ind_ctx_col;
+      M_ = gmx_group_n_mixers(group_);
+      K_ = (parts_ & kIndirect) ? gmx_indirect_n_models(ind_) : 0;
+      n_pad_ = (n_inputs_ + 3) / 4 * 4;
+      mask_words_ = (n_inputs_ + 31) / 32;
+      ls_what_ = gmx_chainstep_what(cs_);
+    } else if (parts != parts_ || lstm_slot != lstm_slot_ || mixer_ctx_col != mixer_ctx_col_ || ind_ctx_col != ind_ctx_col_) {
+      return GMX_ERR_INVALID;
+    }
+    streams_[slot].ls = true;
+    ++ls_participants_;
+    return GMX_OK;
+  }
+  void LeaveLockstep(int slot) {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (streams_[slot].ls) {
+      streams_[slot].ls = false;
+      if (ls_participants_ > 0) --ls_participants_;
+    }
+  }
+  // a stream has recorded what its next step needs: until the step has run
+  void LockstepWait(int slot) {
+    if (yield_)
+      yield_(slot);
+    else
+      StepAll();
+  }
+
   const int S_;
   int device_;
   bool shared_ = false;
+  gmx_chainstep* cs_ = nullptr;
+  uint8_t* ls_what_ = nullptr;
+  int ls_participants_ = 0;
+  std::function<void(int)> yield_;
   static constexpr uint64_t kLstmDrawsFnv = 0xcb25b734d7bec78full;  // FNV-1a over the draws (glibc's rand(): TYPE_3, r[i] = r[i-3] + r[i-31])
   std::vector<int> lstm_init_;
   std::atomic<bool> lstm_from_cache_{false};
@@ -645,6 +716,7 @@ class GpuMixerBank {
   }
   ~GpuMixerBank() {
     if (st().ra) pool_->Leave(slot_);
+    if (st().ls) pool_->LeaveLockstep(slot_);
     {
       std::lock_guard<std::mutex> lk(pool_->mu_);
       st().mixers = nullptr;
@@ -684,6 +756,11 @@ class GpuMixerBank {
     sink_ = nullptr;
     return rc;
   }
+  // Lock step (decoding, MixerPool above): from the next Predict on, this Predictor's device-side models step with the
+  // other Predictors of its pool.  Starts at a byte boundary; every bit Predict -> Perceive -> Learn.
+  int BeginLockstep();
+  // The last bit's Learn goes out (a step of its own) and the stream leaves.
+  int EndLockstep();
   // The same without leaving run-ahead mode (a checkpoint in the middle of a file).
   int SyncRunAhead() {
     if (!st().ra) return GMX_OK;
@@ -842,6 +919,13 @@ class GpuMixerBank {
   void LearnAll(const ShortTermMemory& stm) {
     Settle();
     MixerPool::Stream& s = st();
+    if (s.ls) {  // Mixer::Learn x 33 (and the other device-side models' Learn): asked of the next step
+      if (!ls_predicted_ || status()) return;
+      ls_predicted_ = false;
+      gmx_chainstep_bits(pool_->cs_)[slot_] = (uint8_t)stm.new_bit;
+      pool_->ls_what_[slot_] |= GMX_STEP_LEARN;
+      return;
+    }
     if (s.ra) {
       if (!recorded_ || status()) return;  // (a Learn without its Predict has nothing to learn from)
       recorded_ = false;
@@ -924,6 +1008,7 @@ class GpuMixerBank {
   std::vector<uint8_t> chain_act_;
   std::vector<char> short_cache_, short_in_;
   bool import_pending_ = false, staged_ = false, ever_ran_ = false;
+  bool ls_predicted_ = false;  // lock step: a Predict waits for its Learn
   // run-ahead
   bool recorded_ = false;
   RunAheadSink* sink_ = nullptr;
@@ -1194,6 +1279,7 @@ class GpuIndirectBank {
     Settle();
     Unstage();
     MixerPool::Stream& s = st();
+    if (s.ls) return;  // (lock step: the mixers' Learn asks for the step's learn, which is every device-side model's)
     if (s.ra) {
       s.ibits[s.t] = (uint8_t)stm.new_bit;  // Indirect::Learn x 41, recorded
       return;
@@ -1296,6 +1382,12 @@ inline void GpuIndirectBank::PredictAll(ShortTermMemory& stm) {
   Unstage();
   if (pool_->status()) return;
   MixerPool::Stream& s = st();
+  if (s.ls) {  // lock step: the contexts into the step's records; the mixers' Predict, next in line, waits for the step
+    uint32_t* c = gmx_chainstep_ind_contexts(pool_->cs_) + (size_t)slot_ * models_.size();
+    for (size_t i = 0; i < models_.size(); ++i) c[i] = models_[i]->context();
+    gmx_chainstep_bit_contexts(pool_->cs_)[slot_] = stm.bit_context;
+    return;
+  }
   if (s.ra) {
     // Indirect::Predict x 41, recorded: the contexts as they stand when the last model is called, bit_context
     uint32_t* c = s.ictx + (size_t)s.t * models_.size();
@@ -1389,6 +1481,12 @@ class GpuLstmModel : public Model {
   }
   void Predict(ShortTermMemory& short_term_memory, const LongTermMemory&) override {  // lstm-model.cpp:17-49
     MixerPool::Stream& s = st();
+    if (s.ls) {  // lock step: the PPM byte distribution of a byte that opens; the device walks the bits itself
+      if (short_term_memory.recent_bits == 1)
+        memcpy(gmx_chainstep_ppm(pool_->cs_) + (size_t)slot_ * 256, &short_term_memory.ppm_predictions[0], 1024);
+      range_on_device_ = true;
+      return;
+    }
     if (s.ra) {
       // Lstm::SetInput + Lstm::Predict at a byte boundary, recorded: the PPM byte distribution as it stands
       if (short_term_memory.recent_bits == 1)
@@ -1420,6 +1518,7 @@ class GpuLstmModel : public Model {
     const int current_byte = short_term_memory.recent_bits * 2 + short_term_memory.new_bit;
     if (current_byte < 256) return;
     MixerPool::Stream& s = st();
+    if (s.ls) return;  // (lock step: the device puts the byte together from the bits it is told)
     if (s.ra) {
       s.bytes[s.t / 8] = (uint8_t)(current_byte - 256);  // Lstm::Perceive, recorded
       return;
@@ -1641,6 +1740,41 @@ inline int GpuMixerBank::BeginRunAhead(RunAheadSink* sink, uint64_t chunk_bits) 
   return GMX_OK;
 }
 
+inline int GpuMixerBank::BeginLockstep() {
+  if (st().ra || st().ls) return GMX_ERR_STATE;
+  Settle();
+  MixerPool::Stream& s = st();
+  int parts = MixerPool::kMixers, lstm_slot = -1, mixer_ctx_col = -1, ind_ctx_col = -1;
+  if (s.indirect) {
+    s.indirect->Settle();
+    s.indirect->pending_ = false;
+    s.indirect->SlotsToDevice(stm_);
+    parts |= MixerPool::kIndirect;
+  }
+  if (s.lstm) {
+    if (!(stm_.recent_bits >= 128 || (stm_.recent_bits == 1 && stm_.bits_seen == 0))) return GMX_ERR_STATE;  // (cf. BeginRunAhead)
+    s.lstm->Settle();
+    parts |= MixerPool::kLstm;
+    lstm_slot = s.lstm->prediction_index();
+    for (size_t j = 0; j < mixers_.size(); ++j)
+      if (mixers_[j]->context_address() == &stm_.lstm_prediction_context) mixer_ctx_col = (int)j;
+    if (s.indirect)
+      for (size_t i = 0; i < s.indirect->models_.size(); ++i)
+        if (s.indirect->models_[i]->context_address() == &stm_.lstm_prediction_context) ind_ctx_col = (int)i;
+  }
+  if (status()) return status();
+  ls_predicted_ = false;
+  ever_ran_ = true;
+  return pool_->JoinLockstep(slot_, parts, lstm_slot, mixer_ctx_col, ind_ctx_col);
+}
+
+inline int GpuMixerBank::EndLockstep() {
+  if (!st().ls) return GMX_OK;
+  if (pool_->ls_what_[slot_] & GMX_STEP_LEARN) pool_->LockstepWait(slot_);  // the last bit's Learn: a step without a Predict
+  pool_->LeaveLockstep(slot_);
+  return SlotsHome();
+}
+
 inline int GpuMixerBank::SlotsHome() {
   GpuIndirectBank* ib = st().indirect;
   if (!ib) return status();
@@ -1683,6 +1817,33 @@ inline void GpuMixerBank::PredictAll(ShortTermMemory& stm) {
   Settle();
   if (status()) return;
   MixerPool::Stream& s = st();
+  if (s.ls) {
+    // Mixer::Predict x 33 in lock step: the raw blackboard, active_models as a mask and the contexts read now go into
+    // the step's records; then every other decoder of the pool gets its turn, the step runs, and the outputs are here
+    if (ls_predicted_) {
+      Check("lock step needs Predict -> Perceive -> Learn for every bit", GMX_ERR_STATE);
+      return;
+    }
+    gmx_chainstep* cs = pool_->cs_;
+    const int N = stm.num_predictions;
+    memcpy(gmx_chainstep_predictions(cs) + (size_t)slot_ * pool_->n_pad_, &stm.predictions[0], 4 * (size_t)N);
+    uint32_t* m = gmx_chainstep_active_mask(cs) + (size_t)slot_ * pool_->mask_words_;
+    for (int w = 0; w < pool_->mask_words_; ++w) m[w] = 0;
+    for (int idx : stm.active_models) m[idx >> 5] |= 1u << (idx & 31);
+    uint32_t* c = gmx_chainstep_contexts(cs) + (size_t)slot_ * mixers_.size();
+    for (size_t j = 0; j < mixers_.size(); ++j) c[j] = mixers_[j]->context();
+    pool_->ls_what_[slot_] |= GMX_STEP_PREDICT;
+    ls_predicted_ = true;
+    ever_ran_ = true;
+    pool_->LockstepWait(slot_);
+    if (status()) return;
+    const float* o = gmx_chainstep_outputs(cs) + (size_t)slot_ * mixers_.size();
+    size_t j = 0;
+    for (int k = 0; k < stm.num_layer0_mixers; ++k) stm.mixer_layer0_outputs[k] = o[j++];
+    for (int k = 0; k < stm.num_layer1_mixers; ++k) stm.mixer_layer1_outputs[k] = o[j++];
+    if (j < mixers_.size()) stm.final_mixer_output = o[j];
+    return;
+  }
   if (s.ra) {
     // Mixer::Predict x 33, recorded: the raw blackboard, active_models as a mask, the contexts read now
     if (recorded_) {  // a Predict whose bit was never learned: not a path that runs ahead

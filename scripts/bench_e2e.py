@@ -162,11 +162,87 @@ def measure(streams=1, n_bytes=30000, variant="chain", chunk=2048, verify=True, 
     return out
 
 
+def measure_decode(streams=64, n_bytes=4000, variant="chain", verify=True, cpu=True, device=None):
+    """S files restored side by side (gmx::BatchedDecompressFiles: the reference's own Decoder per file, coder/decoder.cpp:
+    19-39, all files' device-side models ONE gmx_chainstep step per coded bit).  `value` is cold like measure()'s: bits
+    of all files / wall time of the whole `gmix_chain_many -d` process.  The files are first compressed by the same
+    binary (untimed; their bytes are the strict stock build's, measure() checks that); identical_to_stock = every
+    restored file equals its original.  cpu_baseline = the reference's own `gmix -d` at the makefile's -Ofast on the same
+    texts (each compressed by that build's own `gmix -c` first, untimed: -Ofast codes other bytes), whole processes, as
+    many at once as there are files (at most 16)."""
+    exe = os.path.join(DROPIN, EXE[variant])
+    if not os.path.exists(exe):
+        raise RuntimeError(f"{exe} missing (make -C dropin, needs /root/reference)")
+    S = streams
+    dev = ["--device", str(device)] if device is not None else []
+    with tempfile.TemporaryDirectory() as tmp:
+        files, src = [], None
+        for k in range(S):
+            data, src = corpus(n_bytes, 1531 * k)
+            f = os.path.join(tmp, f"f{k:04d}")
+            open(f, "wb").write(data)
+            files.append(f)
+        r = subprocess.run([exe] + dev + [os.path.join(tmp, "c")] + files, capture_output=True, text=True, timeout=1500)
+        if r.returncode != 0:
+            raise RuntimeError(f"{EXE[variant]} failed: {r.stderr[-500:]}")
+        coded = [os.path.join(tmp, "c", f"{k}.gmix") for k in range(S)]
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "-d"] + dev + [os.path.join(tmp, "back")] + coded, capture_output=True, text=True,
+                           timeout=1500)
+        process_seconds = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise RuntimeError(f"{EXE[variant]} -d failed: {r.stderr[-500:]}")
+        st = json.loads(r.stdout.strip().splitlines()[-1])
+        bits = 8.0 * S * n_bytes
+        quota = cpu_quota()
+        out = {"metric": "whole-decompressor bits/sec (the reference's Decoder, feature models and Predictor per file on the "
+                         "host, " + ("33 mixers" if variant == "mixers" else "LSTM + 41 Indirect models + 33 mixers")
+                         + " of all files one device step per coded bit)",
+               "value": bits / process_seconds, "value_coding_loops": st["bits_per_second"], "unit": "bits/s", "n_gpus": 1,
+               "higher_is_better": True, "dtype": "f32", "data": "real text",
+               "config": {"workload": f"{S} file(s) x {n_bytes} bytes of {src}, restored side by side in lock step",
+                          "streams": S, "bytes_per_file": n_bytes, "variant": variant, "worker_threads": st["pinned_cpus"],
+                          "host_cpu": host_cpu(), "cpu_quota_cores": quota},
+               "seconds": process_seconds, "coding_loops_seconds": st["wall_seconds"], "setup_seconds": st["build_seconds"],
+               "in_process_seconds": st["total_seconds"], "steps": st["launches"],
+               "us_per_step": st["wall_seconds"] * 1e6 / max(1, st["launches"])}
+        if verify:
+            out["identical_to_stock"] = all(open(os.path.join(tmp, "back", f"{k}.out"), "rb").read() == open(files[k], "rb").read()
+                                            for k in range(S))
+            out["files_compared"] = S
+        fast = os.path.join(REF, "gmix_fast")
+        if cpu and os.path.exists(fast):
+            n = min(S, 16)
+
+            def each(mode, k):
+                d = os.path.join(tmp, f"x{k}")
+                os.makedirs(d, exist_ok=True)
+                a, b = (files[k], os.path.join(d, "c")) if mode == "-c" else (os.path.join(d, "c"), os.path.join(d, "d"))
+                subprocess.run([fast, mode, a, b], cwd=d, capture_output=True, timeout=1500, check=True)
+            with ThreadPoolExecutor(n) as ex:
+                list(ex.map(lambda k: each("-c", k), range(n)))
+                t0 = time.perf_counter()
+                list(ex.map(lambda k: each("-d", k), range(n)))
+                dt = time.perf_counter() - t0
+            ok = all(open(os.path.join(tmp, f"x{k}", "d"), "rb").read() == open(files[k], "rb").read() for k in range(n))
+            out["vs_cpu"] = out["value"] / (8 * n_bytes * n / dt)
+            out["cpu_baseline"] = {"value": 8 * n_bytes * n / dt, "unit": "bits/s", "cores": n, "kind": "reference",
+                                   "restores_its_input": ok,
+                                   "sample": f"{n} process(es) of the reference's own `gmix -d` at once (whole CLI: Predictor "
+                                             f"construction included), -Ofast -march=x86-64-v3, {n_bytes} bytes each, on "
+                                             f"{host_cpu()}" + (f", cpu quota {quota:g} cores" if quota else "")}
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--bytes", type=int, default=30000)
     ap.add_argument("--variant", default="chain", choices=sorted(EXE))
     ap.add_argument("--chunk", type=int, default=2048)
+    ap.add_argument("--decode", action="store_true", help="measure_decode: S files restored in lock step")
     a = ap.parse_args()
-    print(json.dumps(measure(a.streams, a.bytes, a.variant, a.chunk)))
+    if a.decode:
+        print(json.dumps(measure_decode(a.streams, a.bytes, a.variant)))
+    else:
+        print(json.dumps(measure(a.streams, a.bytes, a.variant, a.chunk)))

@@ -55,6 +55,8 @@ void gmx_group_destroy(gmx_group* g) {
   free(g);
 }
 int gmx_group_n_mixers(const gmx_group* g) { return g ? g->m : GMX_ERR_INVALID; }
+int gmx_group_n_inputs(const gmx_group* g) { return g ? g->n : GMX_ERR_INVALID; }
+int gmx_group_n_streams(const gmx_group* g) { return g ? g->S : GMX_ERR_INVALID; }
 
 int gmx_bank_forward(gmx_group* g, int stream, const float* predictions, const int32_t* active, int n_active,
                      const uint32_t* contexts, float* p_final, float* out_all) {

@@ -393,3 +393,140 @@ int gmx_lstm_feed(gmx_lstm* l, gmx_lstm_batch* b, uint64_t n_bytes, gmx_batch* m
       }
   return GMX_OK;
 }
+
+
+/* ---- gmx_chainstep: S decoders in lock step through LSTM -> Indirect models -> mixers, one step per coded bit
+ * (gmx_amd/csrc/gmx_chainstep.inc), the "device work" done by the oracle stream by stream ---- */
+extern int gmx_group_n_mixers(const gmx_group* g);
+extern int gmx_group_n_inputs(const gmx_group* g);
+extern int gmx_group_n_streams(const gmx_group* g);
+extern int gmx_bank_forward(gmx_group* g, int stream, const float* predictions, const int32_t* active, int n_active,
+                            const uint32_t* contexts, float* p_final, float* out_all);
+extern int gmx_bank_learn(gmx_group* g, int stream, int bit);
+typedef struct cs_stream {
+  int pending, recent_bits, new_bit;
+  uint32_t last_byte, context;
+  float prediction;
+  float cur_ppm[256];
+} cs_stream;
+struct gmx_chainstep {
+  gmx_group* g;
+  gmx_indirect* ib;
+  gmx_lstm* l;
+  int S, n, n_pad, mw, m, k, lstm_slot, mcol, icol;
+  float *pred, *ppm, *p, *outs;
+  uint32_t *mask, *ctx, *ictx, *ibc;
+  uint8_t *bits, *what;
+  cs_stream* st;
+};
+int gmx_chainstep_create(gmx_chainstep** out, gmx_group* g, gmx_indirect* ib, gmx_lstm* l, int lstm_slot, int mixer_ctx_col,
+                         int ind_ctx_col) {
+  if (!out || !g) return GMX_ERR_INVALID;
+  gmx_chainstep* cs = (gmx_chainstep*)calloc(1, sizeof *cs);
+  cs->g = g;
+  cs->ib = ib;
+  cs->l = l;
+  cs->S = gmx_group_n_streams(g);
+  cs->n = gmx_group_n_inputs(g);
+  cs->m = gmx_group_n_mixers(g);
+  cs->n_pad = (cs->n + 3) / 4 * 4;
+  cs->mw = (cs->n + 31) / 32;
+  cs->k = ib ? ib->n : 0;
+  cs->lstm_slot = lstm_slot;
+  cs->mcol = l ? mixer_ctx_col : -1;
+  cs->icol = (l && ib) ? ind_ctx_col : -1;
+  const size_t S = (size_t)cs->S;
+  cs->pred = (float*)calloc(S * cs->n_pad, 4);
+  cs->mask = (uint32_t*)calloc(S * cs->mw, 4);
+  cs->ctx = (uint32_t*)calloc(S * cs->m, 4);
+  cs->ictx = (uint32_t*)calloc(S * (cs->k ? cs->k : 1), 4);
+  cs->ibc = (uint32_t*)calloc(S, 4);
+  cs->ppm = (float*)calloc(S * 256, 4);
+  cs->p = (float*)calloc(S, 4);
+  cs->outs = (float*)calloc(S * cs->m, 4);
+  cs->bits = (uint8_t*)calloc(S, 1);
+  cs->what = (uint8_t*)calloc(S, 1);
+  cs->st = (cs_stream*)calloc(S, sizeof(cs_stream));
+  for (int s = 0; s < cs->S; ++s) cs->st[s].recent_bits = 1;
+  *out = cs;
+  return GMX_OK;
+}
+void gmx_chainstep_destroy(gmx_chainstep* cs) {
+  if (!cs) return;
+  void* v[] = {cs->pred, cs->mask, cs->ctx, cs->ictx, cs->ibc, cs->ppm, cs->p, cs->outs, cs->bits, cs->what, cs->st};
+  for (size_t i = 0; i < sizeof v / sizeof v[0]; ++i) free(v[i]);
+  free(cs);
+}
+int gmx_chainstep_n_streams(const gmx_chainstep* cs) { return cs ? cs->S : GMX_ERR_INVALID; }
+float* gmx_chainstep_predictions(gmx_chainstep* cs) { return cs->pred; }
+uint32_t* gmx_chainstep_active_mask(gmx_chainstep* cs) { return cs->mask; }
+uint32_t* gmx_chainstep_contexts(gmx_chainstep* cs) { return cs->ctx; }
+uint32_t* gmx_chainstep_ind_contexts(gmx_chainstep* cs) { return cs->ib ? cs->ictx : 0; }
+uint32_t* gmx_chainstep_bit_contexts(gmx_chainstep* cs) { return cs->ib ? cs->ibc : 0; }
+float* gmx_chainstep_ppm(gmx_chainstep* cs) { return cs->l ? cs->ppm : 0; }
+uint8_t* gmx_chainstep_bits(gmx_chainstep* cs) { return cs->bits; }
+uint8_t* gmx_chainstep_what(gmx_chainstep* cs) { return cs->what; }
+const float* gmx_chainstep_p(gmx_chainstep* cs) { return cs->p; }
+const float* gmx_chainstep_outputs(gmx_chainstep* cs) { return cs->outs; }
+int gmx_chainstep_step(gmx_chainstep* cs) {
+  if (!cs) return GMX_ERR_INVALID;
+  for (int s = 0; s < cs->S; ++s) {
+    const uint8_t w = cs->what[s];
+    cs_stream* st = &cs->st[s];
+    if ((w & GMX_STEP_LEARN) && !st->pending) return GMX_ERR_STATE;
+    if ((w & GMX_STEP_PREDICT) && st->pending && !(w & GMX_STEP_LEARN)) return GMX_ERR_STATE;
+  }
+  for (int s = 0; s < cs->S; ++s) {
+    const uint8_t w = cs->what[s];
+    cs_stream* st = &cs->st[s];
+    float* pr = cs->pred + (size_t)s * cs->n_pad;
+    uint32_t* mk = cs->mask + (size_t)s * cs->mw;
+    uint32_t* cx = cs->ctx + (size_t)s * cs->m;
+    uint32_t* icx = cs->ictx + (size_t)s * (cs->k ? cs->k : 1);
+    if (w & GMX_STEP_LEARN) {
+      const int bit = cs->bits[s] ? 1 : 0;
+      gmx_bank_learn(cs->g, s, bit);
+      if (cs->ib) gmxo_ind_learn(cs->ib->bs[s], bit);
+      if (cs->l) gmxo_lstm_model_learn(cs->l->st[s].l, st->recent_bits, bit);
+      st->new_bit = bit;
+      st->recent_bits += st->recent_bits + bit;
+      if (st->recent_bits >= 256) {
+        st->last_byte = (uint32_t)(st->recent_bits - 256);
+        st->recent_bits = 1;
+      }
+      st->pending = 0;
+    }
+    if (w & GMX_STEP_PREDICT) {
+      if (cs->l) {
+        if (st->recent_bits == 1) memcpy(st->cur_ppm, cs->ppm + (size_t)s * 256, sizeof st->cur_ppm);
+        const int act = gmxo_lstm_model_predict(cs->l->st[s].l, st->recent_bits, st->last_byte, st->new_bit, st->cur_ppm,
+                                                &st->prediction, &st->context, 0);
+        pr[cs->lstm_slot] = st->prediction;
+        if (act)
+          mk[cs->lstm_slot >> 5] |= 1u << (cs->lstm_slot & 31);
+        else
+          mk[cs->lstm_slot >> 5] &= ~(1u << (cs->lstm_slot & 31));
+        if (cs->mcol >= 0) cx[cs->mcol] = st->context;
+        if (cs->icol >= 0) icx[cs->icol] = st->context;
+      }
+      if (cs->ib) {
+        float ip[128];
+        uint8_t ia[128];
+        gmxo_ind_predict(cs->ib->bs[s], icx, cs->ibc[s], ip, ia);
+        for (int i = 0; i < cs->k; ++i)
+          for (int h = 0; h < 2; ++h) {
+            const int slot = cs->ib->slot[i][h];
+            pr[slot] = ip[2 * i + h];
+            if (ia[2 * i + h]) mk[slot >> 5] |= 1u << (slot & 31);
+          }
+      }
+      int32_t act[2048];
+      int na = 0;
+      for (int i = 0; i < cs->n; ++i)
+        if (mk[i >> 5] >> (i & 31) & 1u) act[na++] = i;
+      gmx_bank_forward(cs->g, s, pr, act, na, cx, &cs->p[s], cs->outs + (size_t)s * cs->m);
+      st->pending = 1;
+    }
+  }
+  return GMX_OK;
+}

@@ -94,3 +94,23 @@ def test_predictors_built_side_by_side_where_no_constructor_draws(tmp_path, exe,
     for k, f in enumerate(files):
         gmix("gmix_strict", "-c", f, tmp_path / f"ref{k}", tmp_path)
         assert (tmp_path / f"ref{k}").read_bytes() == (tmp_path / "out" / f"{k}.gmix").read_bytes(), f"file {k}"
+
+
+@pytest.mark.parametrize("exe,cpus", [("gmix_many_shim", 2), ("gmix_chain_many_shim", 3), ("gmix_chain_many_shim", 1)])
+def test_many_files_restored_in_lock_step(tmp_path, exe, cpus):
+    """gmx::BatchedDecompressFiles: five files the STOCK build compressed (0 / 1 / 613 / 300 / 613 bytes) restored
+    together -- the reference's own Decoder per file, each on a fibre, `cpus` worker threads, one gmx_chainstep step per
+    coded bit for all of them; files that end early sit the remaining steps out, every file's last Learn is a step
+    without a Predict.  Byte-identical to the inputs."""
+    _skip_unless("gmix_strict", exe)
+    files, coded = [], []
+    for k, n in enumerate((0, 1, 613, 300, 613)):
+        f = tmp_path / f"f{k}"
+        f.write_bytes(corpus(n, 3000 * k))
+        files.append(f)
+        gmix("gmix_strict", "-c", f, tmp_path / f"c{k}", tmp_path)
+        coded.append(tmp_path / f"c{k}")
+    st = run_many(exe, coded, tmp_path / "back", 2048, extra=("-d", "--cpus", str(cpus)))
+    assert st["mode"] == "decompress" and st["failed"] == 0 and st["launches"] >= 8 * 613 + 1
+    for k, f in enumerate(files):
+        assert (tmp_path / "back" / f"{k}.out").read_bytes() == f.read_bytes(), f"file {k}"

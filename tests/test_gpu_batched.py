@@ -105,3 +105,31 @@ def test_state_left_behind_equals_the_per_bit_loop(gpu, tmp_path):
     (stock,) = run_all([("ref_tester_strict", 0)], 40000, tmp_path)
     for exe, chunk in (("gmix_batched_ckpt", 2048), ("gmix_chain_batched_ckpt", 1000)):
         same_checkpoint(os.path.join(stock, "restart"), checkpoint_after_batches(exe, stock, 40000, chunk, tmp_path))
+
+
+@pytest.mark.parametrize("exe,n_files,base", [("gmix_chain_many", 64, 1500), ("gmix_many", 8, 600)])
+def test_files_restored_side_by_side_in_lock_step(gpu, tmp_path, exe, n_files, base):
+    """gmx::BatchedDecompressFiles on the device: the reference's own Decoder (coder/decoder.cpp:19-39) per file, each on
+    a fibre of a few worker threads; every coded bit of all files is ONE gmx_chainstep step -- LSTM, 41 Indirect models and
+    33 mixers of all streams in one hipGraph (gmix_many: the mixers alone).  Files the run-ahead compressor wrote AND
+    files the stock build wrote (`gmix_strict -c`) are restored byte for byte; lengths differ, so streams leave one by
+    one."""
+    need("gmix_strict", exe)
+    files = []
+    for k in range(n_files):
+        f = tmp_path / f"f{k}"
+        f.write_bytes(corpus(base + 37 * k, 1531 * k))
+        files.append(f)
+    st = run_many(exe, files, tmp_path / "c", 2048)
+    assert st["failed"] == 0
+    coded = [tmp_path / "c" / f"{k}.gmix" for k in range(n_files)]
+    for k in (0, n_files // 2, n_files - 1):   # ... and the stock build's own files among them
+        gmix("gmix_strict", "-c", files[k], tmp_path / f"stock{k}", tmp_path)
+        assert (tmp_path / f"stock{k}").read_bytes() == coded[k].read_bytes()
+        coded[k] = tmp_path / f"stock{k}"
+    st = run_many(exe, coded, tmp_path / "back", 2048, extra=("-d",))
+    assert st["mode"] == "decompress" and st["failed"] == 0
+    for k, f in enumerate(files):
+        assert (tmp_path / "back" / f"{k}.out").read_bytes() == f.read_bytes(), f"file {k}"
+    print(f"{exe} -d, {n_files} files: {st['bits_per_second']:.3g} bits/s aggregate over {st['wall_seconds']:.2f} s, "
+          f"{st['launches']} steps = {st['wall_seconds'] / st['launches'] * 1e6:.1f} us per step")
