@@ -336,9 +336,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="only the headline workload")
     ap.add_argument("--only-also", default="", help="comma-separated: of the also{} entries, only these")
-    ap.add_argument("--e2e-bytes", type=int, default=30000, help="bytes per file of the also.e2e_* entries")
-    ap.add_argument("--decode-bytes", type=int, default=4000, help="bytes per file of also.e2e_decode")
-    ap.add_argument("--decode-streams", type=int, default=64, help="files of also.e2e_decode")
+    ap.add_argument("--e2e-bytes", type=int, default=30000, help="bytes of the one file of also.e2e_S1 / e2e_S1_mixers")
+    ap.add_argument("--e2e-many-bytes", type=int, default=100000, help="bytes per file of also.e2e_S64")
+    ap.add_argument("--decode-bytes", type=int, default=6000, help="bytes per file of also.e2e_decode")
+    ap.add_argument("--decode-streams", type=int, default=256, help="files of also.e2e_decode")
     ap.add_argument("--rehearse-cpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-sample-bits", type=int, default=None,
                     help="bits of the same stream for the one-core reference (default: about 5-15 s of CPU work)")
@@ -439,7 +440,7 @@ def main():
                             continue
                         also[name] = mod.measure_decode(streams=args.decode_streams, n_bytes=args.decode_bytes)
                     elif script == "bench_e2e.py":
-                        also[name] = mod.measure(n_bytes=args.e2e_bytes, **kw)
+                        also[name] = mod.measure(n_bytes=args.e2e_many_bytes if kw["streams"] > 1 else args.e2e_bytes, **kw)
                     else:
                         also[name] = mod.measure(**kw)
                     if args.no_cpu_baseline:
@@ -461,9 +462,9 @@ def main():
             n_files = mod.files_that_fit(64, world)
             mine = {"value": -1.0, "seconds": -1.0, "bits": 0.0}
             try:
-                r = mod.measure(streams=n_files, n_bytes=args.e2e_bytes, variant="chain", device=local_rank,
+                r = mod.measure(streams=n_files, n_bytes=args.e2e_many_bytes, variant="chain", device=local_rank,
                                 verify=(rank == 0), cpu=False, before=comm.barrier)
-                mine = {"value": r["value"], "seconds": r["seconds"], "bits": 8.0 * n_files * args.e2e_bytes}
+                mine = {"value": r["value"], "seconds": r["seconds"], "bits": 8.0 * n_files * args.e2e_many_bytes}
             except Exception as e:
                 r = {"error": f"{type(e).__name__}: {e}"}
             comm.barrier()

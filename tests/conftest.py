@@ -11,6 +11,17 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU check (still part of -m 'not gpu')")
+    config.addinivalue_line("markers", "report: prints a measurement or rehearses bench.py over RCCL, asserts little: "
+                                       "runs only with GMX_LONG_TESTS=1 (keeps `-m gpu` inside its time limit)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("GMX_LONG_TESTS"):
+        return
+    skip = pytest.mark.skip(reason="a report, not a check: GMX_LONG_TESTS=1 runs it")
+    for item in items:
+        if "report" in item.keywords:
+            item.add_marker(skip)
 
 
 def _have_gpu():

@@ -50,10 +50,10 @@ def test_reference_tester_with_batched_compression_equals_stock(gpu, tmp_path):
 def test_64_files_side_by_side_equal_stock(gpu, tmp_path, exe):
     """64 Predictors on 64 host threads, their mixers 64 streams of ONE gmx_group (gmix_chain_many: and their LSTMs
     and Indirect models 64 streams of one gmx_lstm / gmx_indirect), one launch per bank and 2 048-bit chunk for all of
-    them; files of 30 000 .. 36 300 bytes (8 000 .. 14 300 with the mixers alone on the device) starting at different
+    them; files of 12 000 .. 18 300 bytes (3 000 .. 9 300 with the mixers alone on the device) starting at different
     places of the corpus, so they end in different rounds.  Every output is the stock build's `gmix -c` of the same file."""
     need("gmix_strict", exe)
-    base = 30000 if exe == "gmix_chain_many" else 8000   # (mixers only: the host's 88 feature models make it 9 us per bit)
+    base = 12000 if exe == "gmix_chain_many" else 3000   # (mixers only: the host's 88 feature models make it 9 us per bit)
     files = []
     for k in range(64):
         f = tmp_path / f"f{k}"
@@ -97,14 +97,14 @@ def test_small_chunks_and_ragged_ends(gpu, tmp_path, exe, chunk):
 
 def test_state_left_behind_equals_the_per_bit_loop(gpu, tmp_path):
     """What a run-ahead compression LEAVES on the device and on the blackboard: Predictor::WriteCheckpoint straight
-    after gmx::BatchedCompressor over 20 001 bytes (79 chunks of 2 048 bits and a ragged one; chain: 161 of 1 000)
+    after gmx::BatchedCompressor over 8 001 bytes (31 chunks of 2 048 bits and a ragged one; chain: 65 of 1 000)
     equals the checkpoint the stock tester writes after the same bytes through its per-bit loop
     (tester.cpp:32-59): the three banks' state as the reference's serialisers write it, the mixers' outputs, the
     Indirect models' and the LSTM's prediction slots (gmx_indirect_slots_get) and lstm_prediction_context."""
     need("ref_tester_strict", "gmix_batched_ckpt", "gmix_chain_batched_ckpt")
-    (stock,) = run_all([("ref_tester_strict", 0)], 40000, tmp_path)
+    (stock,) = run_all([("ref_tester_strict", 0)], 16000, tmp_path)
     for exe, chunk in (("gmix_batched_ckpt", 2048), ("gmix_chain_batched_ckpt", 1000)):
-        same_checkpoint(os.path.join(stock, "restart"), checkpoint_after_batches(exe, stock, 40000, chunk, tmp_path))
+        same_checkpoint(os.path.join(stock, "restart"), checkpoint_after_batches(exe, stock, 16000, chunk, tmp_path))
 
 
 @pytest.mark.parametrize("exe,n_files,base", [("gmix_chain_many", 64, 1500), ("gmix_many", 8, 600)])

@@ -154,6 +154,7 @@ def test_two_groups_and_protocol_errors(gpu, oracle):
     gc.close()
 
 
+@pytest.mark.report
 def test_per_bit_latency_report(gpu, capsys):
     """Not a parity test: records what a Predict+Learn pair costs through the C ABI."""
     topo = topology.stock(90)

@@ -55,6 +55,7 @@ def test_compressed_sizes_gathered_over_rccl(gpu, oracle, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.report
 def test_bench_multi_rank_path_over_rccl(gpu):
     """bench.py's N > 1 code path (init nccl, barrier, MAX/SUM all-reduce) with one rank per visible GPU."""
     n = _n_gpus()
@@ -72,6 +73,7 @@ def test_bench_multi_rank_path_over_rccl(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.report
 def test_bench_whole_files_on_every_rank(gpu):
     """bench.py across ranks also compresses whole files on every GPU (64 files per rank on the rank's own device, a
     process per GPU, nothing exchanged but the figures): also.e2e_S64 carries every rank's rate and the aggregate."""
@@ -80,7 +82,7 @@ def test_bench_whole_files_on_every_rank(gpu):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--streams", "256", "--bits", "128",
-                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--only-also", "e2e_S64", "--e2e-bytes", "6000"],
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--only-also", "e2e_S64", "--e2e-many-bytes", "6000"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
