@@ -676,43 +676,58 @@ gmx_indirect_step_kernel(const GmxIndDev* __restrict__ dv, const GmxIndStepArgs 
   const bool on = lane < K;
   uint8_t* const bank = a.banks + (uint64_t)s * dv->bank_bytes;
   uint32_t* const L = a.latch + ((uint64_t)s * 64 + lane) * 4;  // {index, entry, have, -}
-  uint64_t act_a = 0, act_b = 0;
-  float va = 0.f, vb = 0.f;
   GmxIndModelDev d = dv->m[on ? lane : 0];
   if (on) {
+    // Three dependent trips to memory instead of the seven of learn-then-predict written out in order: (1) everything
+    // that depends on nothing -- the latch, the step's context, the slots; (2) the learn's two logits AND the predict's
+    // table entry; (3) the predict's two logits.  What the learn writes and the predict would read again -- the entry,
+    // when the index repeats; a logit, when the state does -- is handed over in registers; the stores go out last.
     uint16_t* const tab = (uint16_t*)(bank + d.tab_off);
     float* const nsp = (float*)(bank + dv->pred_off) + (size_t)lane * 512;
     float* const rmp = nsp + 256;
     float* const slots = (float*)(bank + dv->slots_off);
-    uint32_t idx = L[0], e = L[1], have = L[2];
-    if ((what & 1u) && have) {
-      const int bit = a.bits[s] ? 1 : 0;
-      const uint32_t ns = e & 255u, rm = e >> 8;
-      const uint32_t sn = ns != 255u ? ns : 0u;  // the uninitialised state learns as state 0
-      const float pa = nsp[sn], qb = rmp[rm];
-      const float na = pa + ((float)bit - gmx_logistic_tab(pa, s_tab)) * d.lr;
-      const float nb = qb + ((float)bit - gmx_logistic_tab(qb, s_tab)) * d.lr;
-      nsp[sn] = na;
-      rmp[rm] = nb;
-      tab[idx] = (uint16_t)((uint32_t)nsn[2 * sn + bit] | ((uint32_t)rmn[2 * rm + bit] << 8));
-      have = 0;
-      __threadfence();  // this lane's own loads below may hit the same entry and logits
+    const uint32_t idx_old = L[0], e_old = L[1];
+    uint32_t have = L[2];
+    const bool do_learn = (what & 1u) && have;
+    const bool do_pred = (what & 2u) != 0;
+    const int bit = a.bits[s] ? 1 : 0;
+    const uint32_t ctx = do_pred ? a.ctx[(uint64_t)s * K + lane] : 0u;
+    const uint32_t bcu = do_pred ? a.bc[s] : 0u;
+    float va = slots[2 * lane], vb = slots[2 * lane + 1];
+    // ---- trip 2
+    const uint32_t ns_o = e_old & 255u, rm_o = e_old >> 8;
+    const uint32_t sn_o = ns_o != 255u ? ns_o : 0u;  // the uninitialised state learns as state 0
+    float pa = 0.f, pb = 0.f;
+    if (do_learn) {
+      pa = nsp[sn_o];
+      pb = rmp[rm_o];
     }
-    if (what & 2u) {
-      const uint32_t ctx = a.ctx[(uint64_t)s * K + lane];
-      idx = ((ctx << 8) + a.bc[s]) % d.size;  // indirect.cpp:31-32, 32-bit wrap
+    uint32_t idx = idx_old, e = e_old;
+    if (do_pred) {
+      idx = ((ctx << 8) + bcu) % d.size;  // indirect.cpp:31-32, 32-bit wrap
       e = tab[idx];
+    }
+    float na = 0.f, nb = 0.f;
+    uint32_t e_upd = 0;
+    if (do_learn) {  // Indirect::Learn (indirect.cpp:48-69)
+      na = pa + ((float)bit - gmx_logistic_tab(pa, s_tab)) * d.lr;
+      nb = pb + ((float)bit - gmx_logistic_tab(pb, s_tab)) * d.lr;
+      e_upd = (uint32_t)nsn[2 * sn_o + bit] | ((uint32_t)rmn[2 * rm_o + bit] << 8);
+      if (do_pred && idx == idx_old) e = e_upd;
+      have = 0;
+    }
+    if (do_pred) {  // Indirect::Predict (indirect.cpp:28-46)
       const uint32_t ns = e & 255u, rm = e >> 8;
       const bool seen_a = ns != 255u, seen_b = rm != 0u;  // never-seen states leave the slot alone
-      va = slots[2 * lane];
-      vb = slots[2 * lane + 1];
-      const float qa = seen_a ? nsp[ns] : 0.f, qb = seen_b ? rmp[rm] : 0.f;
+      // ---- trip 3
+      float qa = 0.f, qb = 0.f;
+      if (seen_a) qa = (do_learn && ns == sn_o) ? na : nsp[ns];
+      if (seen_b) qb = (do_learn && rm == rm_o) ? nb : rmp[rm];
       if (seen_a) slots[2 * lane] = va = qa;
       if (seen_b) slots[2 * lane + 1] = vb = qb;
-      if (seen_a && qa != 0.f) atomicOr(&mwl[d.slot_a >> 5], 1u << (d.slot_a & 31));  // a zero logit is stored, not active
-      if (seen_b && qb != 0.f) atomicOr(&mwl[d.slot_b >> 5], 1u << (d.slot_b & 31));
-      act_a = seen_a && qa != 0.f;
-      act_b = seen_b && qb != 0.f;
+      const bool act_a = seen_a && qa != 0.f, act_b = seen_b && qb != 0.f;  // a zero logit is stored, not active
+      if (act_a) atomicOr(&mwl[d.slot_a >> 5], 1u << (d.slot_a & 31));
+      if (act_b) atomicOr(&mwl[d.slot_b >> 5], 1u << (d.slot_b & 31));
       have = 1;
       if (a.mx_pred) {
         float* const mp = a.mx_pred + (uint64_t)s * a.mx_n_pad;
@@ -725,6 +740,11 @@ gmx_indirect_step_kernel(const GmxIndDev* __restrict__ dv, const GmxIndStepArgs 
         a.act_out[((uint64_t)s * K + lane) * 2] = (uint8_t)act_a;
         a.act_out[((uint64_t)s * K + lane) * 2 + 1] = (uint8_t)act_b;
       }
+    }
+    if (do_learn) {
+      nsp[sn_o] = na;
+      rmp[rm_o] = nb;
+      tab[idx_old] = (uint16_t)e_upd;
     }
     L[0] = idx;
     L[1] = e;

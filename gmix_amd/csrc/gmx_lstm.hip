@@ -862,7 +862,7 @@ extern "C" hipError_t gmx_launch_lstm_scatter(const GmxLstmScatterArgs* args, in
 // One wave per stream; the two ordered sums (std::accumulate from the first element up) are one lane's.
 __global__ void __launch_bounds__(64)
 gmx_lstm_bitstep_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmBitArgs a) {
-  __shared__ float pr[GMX_L_NO];
+  __shared__ __attribute__((aligned(16))) float pr[GMX_L_NO];
   const int s = blockIdx.x, lane = threadIdx.x;
   const uint32_t what = a.what[s];
   if (!(what & 2u)) return;
@@ -886,10 +886,28 @@ gmx_lstm_bitstep_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmBitArgs
       top = mid_before;
   }
   const int mid = bot + ((top - bot) / 2);
-  float num = 0.0f;
-  for (int i = mid + 1; i <= top; ++i) num += pr[i];
-  float denom = num;
-  for (int i = bot; i <= mid; ++i) denom += pr[i];
+  // std::accumulate from the first element up, over the upper half, then on over the lower half.  The halves are
+  // powers of two long and aligned to their length: sixteen values are fetched at a time, added one after the other
+  // (the adds wait for their batch, not each for its own read).
+  auto ordered = [&](float acc, int lo, int n) {
+    int i = lo;
+    for (; n >= 16; n -= 16, i += 16) {
+      const float4 q0 = *(const float4*)(pr + i), q1 = *(const float4*)(pr + i + 4), q2 = *(const float4*)(pr + i + 8),
+                   q3 = *(const float4*)(pr + i + 12);
+      acc += q0.x; acc += q0.y; acc += q0.z; acc += q0.w;
+      acc += q1.x; acc += q1.y; acc += q1.z; acc += q1.w;
+      acc += q2.x; acc += q2.y; acc += q2.z; acc += q2.w;
+      acc += q3.x; acc += q3.y; acc += q3.z; acc += q3.w;
+    }
+    for (; n >= 4; n -= 4, i += 4) {
+      const float4 q = *(const float4*)(pr + i);
+      acc += q.x; acc += q.y; acc += q.z; acc += q.w;
+    }
+    for (; n > 0; --n, ++i) acc += pr[i];
+    return acc;
+  };
+  const float num = ordered(0.0f, mid + 1, top - mid);
+  const float denom = ordered(num, bot, mid - bot + 1);
   float prediction = __uint_as_float(scal[5]);
   bool active = false;
   if (denom != 0.0f) {  // (a silent bit leaves the slot as it was)

@@ -641,12 +641,14 @@ class LockstepRunner {
     Fiber* f = Current();
     gmx_fiber_switch(&f->sp, f->sched_sp);
   }
-  // `setup(worker)` on every worker thread first (pinning, Predictor construction), then the fibres until all have
-  // ended; `step()` by one thread whenever every live fibre waits.  Returns the steps taken.
-  uint64_t Run(const std::function<void(int)>& setup, const std::function<int()>& step) {
+  // `setup(worker)` on every worker thread first (Predictor construction), then -- all of them done -- `join(worker)`
+  // (device banks, on the threads' own stacks), then the fibres until all have ended; `step()` by one thread, on its
+  // own stack, whenever every live fibre waits.  Returns the steps taken.
+  uint64_t Run(const std::function<void(int)>& setup, const std::function<void(int)>& join,
+               const std::function<int()>& step) {
     std::vector<std::thread> threads;
     live_.store((int)fibers_.size());
-    for (int w = 0; w < W_; ++w) threads.emplace_back([&, w] { Work(w, setup, step); });
+    for (int w = 0; w < W_; ++w) threads.emplace_back([&, w] { Work(w, setup, join, step); });
     for (auto& t : threads) t.join();
     return steps_;
   }
@@ -688,8 +690,11 @@ class LockstepRunner {
       }
     }
   }
-  void Work(int w, const std::function<void(int)>& setup, const std::function<int()>& step) {
+  void Work(int w, const std::function<void(int)>& setup, const std::function<void(int)>& join,
+            const std::function<int()>& step) {
     setup(w);
+    Barrier([] {});
+    join(w);
     Barrier([] {});
     std::vector<Fiber*> mine;
     for (size_t i = w; i < fibers_.size(); i += W_)
@@ -776,13 +781,26 @@ inline int BatchedDecompressFiles(std::vector<BatchedJob>& jobs, const BatchedOp
     worker_pinned[w] = 1;
     if (opt.pin_threads && PinThreadToDeviceNode(pool.device(), W)) ++pinned;
   };
+  // A fibre runs the reference's Decoder and nothing that calls the device: the banks are brought up and joined
+  // (BeginLockstep) on the worker threads' own stacks before the fibres start, every step is taken there too, and a
+  // fibre's last act is the wait for its last Learn.  (Runtime and profiler code on a 1 MB foreign stack: rocprofv3
+  // around this very loop died with a segmentation fault while BeginLockstep still ran inside the fibres.)
+  std::vector<std::shared_ptr<GpuMixerBank>> banks(S);
   for (int s = 0; s < S; ++s) {
     runner.Add(s, [&, s] {
       BatchedJob& job = jobs[s];
-      pin(s % W);  // (where constructors draw from rand() the threads are only pinned now, with every Predictor standing)
-      if (job.status || !preds[s]) return;
+      if (job.status || !banks[s]) return;
       const clock::time_point a = clock::now();
-      job.status = LockstepDecompress(job.output_bytes, &in[s], &out[s], preds[s].get());
+      {
+        Decoder d(&in[s], preds[s].get());  // runner_utils::Decompress (runner-utils.cpp:69-86), bit by bit
+        for (unsigned long long pos = 0; pos < job.output_bytes && banks[s]->status() == 0; ++pos) {
+          int byte = 1;
+          while (byte < 256) byte += byte + d.Decode();
+          out[s].put(byte);
+        }
+      }
+      banks[s]->FinishLockstep();
+      job.status = banks[s]->status();
       job.seconds = std::chrono::duration<double>(clock::now() - a).count();
       out[s].close();
     });
@@ -824,8 +842,23 @@ inline int BatchedDecompressFiles(std::vector<BatchedJob>& jobs, const BatchedOp
       }
     }
   };
+  // ... and, every Predictor standing: the device banks (the first to get here creates them for all), each stream's join
+  auto join = [&](int w) {
+    pin(w);  // (where constructors draw from rand() the threads are only pinned now)
+    for (int s = w; s < S; s += W) {
+      if (!preds[s] || jobs[s].status) continue;
+      banks[s] = GpuMixerBank::Of(preds[s].get(), sizeof(Predictor));
+      if (!banks[s]) {
+        fprintf(stderr, "gmx::BatchedDecompressFiles: this Predictor's mixers are not gmx::GpuMixer\n");
+        jobs[s].status = GMX_ERR_INVALID;
+        continue;
+      }
+      jobs[s].status = banks[s]->BeginLockstep();
+      if (jobs[s].status) banks[s].reset();
+    }
+  };
   bool started = false;
-  const uint64_t steps = runner.Run(setup, [&] {
+  const uint64_t steps = runner.Run(setup, join, [&] {
     if (!started) {
       started = true;
       t0 = clock::now();  // (the first step: every fibre has built nothing more than its first record)

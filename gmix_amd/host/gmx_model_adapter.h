@@ -759,8 +759,10 @@ class GpuMixerBank {
   // Lock step (decoding, MixerPool above): from the next Predict on, this Predictor's device-side models step with the
   // other Predictors of its pool.  Starts at a byte boundary; every bit Predict -> Perceive -> Learn.
   int BeginLockstep();
-  // The last bit's Learn goes out (a step of its own) and the stream leaves.
+  // The last bit's Learn goes out (a step of its own) and the stream leaves; the device-side models' blackboard slots
+  // come home (a device call).  FinishLockstep is the first half alone -- no device call: a fibre may run it.
   int EndLockstep();
+  void FinishLockstep();
   // The same without leaving run-ahead mode (a checkpoint in the middle of a file).
   int SyncRunAhead() {
     if (!st().ra) return GMX_OK;
@@ -1768,10 +1770,15 @@ inline int GpuMixerBank::BeginLockstep() {
   return pool_->JoinLockstep(slot_, parts, lstm_slot, mixer_ctx_col, ind_ctx_col);
 }
 
-inline int GpuMixerBank::EndLockstep() {
-  if (!st().ls) return GMX_OK;
+inline void GpuMixerBank::FinishLockstep() {
+  if (!st().ls) return;
   if (pool_->ls_what_[slot_] & GMX_STEP_LEARN) pool_->LockstepWait(slot_);  // the last bit's Learn: a step without a Predict
   pool_->LeaveLockstep(slot_);
+}
+
+inline int GpuMixerBank::EndLockstep() {
+  if (!st().ls) return GMX_OK;
+  FinishLockstep();
   return SlotsHome();
 }
 

@@ -422,8 +422,9 @@ int gmx_lstm_memory_usage(gmx_lstm* l, uint64_t* bytes);
  *                     [s][mask_words] (their bits left clear), contexts[s][M], ind_contexts[s][K], bit_contexts[s], and
  *                     -- when the bit opens a byte -- ppm[s][256] (ShortTermMemory::ppm_predictions): Predictor::Predict
  * and calls gmx_chainstep_step, which returns with p[s] (and outputs[s][M]) of the streams that predicted.  A stream
- * whose what[s] is 0 sits the step out (its file has ended); streams start at a byte boundary.  One hipGraph per step
- * (two uploads, the kernels, one download); same floats as every other surface.  Destroy before the banks. */
+ * whose what[s] is 0 sits the step out (its file has ended) -- but not between a Predict and its Learn: the Learn belongs
+ * to the very next step (GMX_ERR_STATE otherwise); streams start at a byte boundary.  One hipGraph of kernels per step;
+ * same floats as every other surface.  Destroy before the banks. */
 #define GMX_STEP_LEARN 1u
 #define GMX_STEP_PREDICT 2u
 typedef struct gmx_chainstep gmx_chainstep;

@@ -476,6 +476,13 @@ int gmx_chainstep_step(gmx_chainstep* cs) {
     if ((w & GMX_STEP_LEARN) && !st->pending) return GMX_ERR_STATE;
     if ((w & GMX_STEP_PREDICT) && st->pending && !(w & GMX_STEP_LEARN)) return GMX_ERR_STATE;
   }
+  {
+    int any = 0;
+    for (int s = 0; s < cs->S; ++s) any |= cs->what[s];
+    if (!any) return GMX_OK;
+    for (int s = 0; s < cs->S; ++s)  /* a Learn belongs to the step right behind its Predict (gmxmix.h) */
+      if (cs->st[s].pending && !(cs->what[s] & GMX_STEP_LEARN)) return GMX_ERR_STATE;
+  }
   for (int s = 0; s < cs->S; ++s) {
     const uint8_t w = cs->what[s];
     cs_stream* st = &cs->st[s];

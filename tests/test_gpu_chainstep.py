@@ -143,8 +143,15 @@ def test_step_protocol_errors(gpu):
     cs.step()
     with pytest.raises(gpu.GmxError):   # a second Predict before the first was learned from
         cs.step()
+    cs.what[:] = [LEARN | PREDICT, 0]
+    with pytest.raises(gpu.GmxError):   # stream 1 sits out between its Predict and its Learn
+        cs.step()
     cs.what[:] = [LEARN | PREDICT, LEARN]
     cs.bits[:] = [1, 0]
+    cs.step()
+    cs.what[:] = [0, 0]
+    cs.step()                            # nobody asks: nothing happens
+    cs.what[:] = [LEARN, 0]
     cs.step()
     cs.close()
     mg.close()
