@@ -759,7 +759,10 @@ inline int BatchedDecompressFiles(std::vector<BatchedJob>& jobs, const BatchedOp
   BatchedOptions opt = opt_in;
   const int S = (int)jobs.size();
   if (S == 0) return 0;
-  int W = opt.max_cpus > 0 ? opt.max_cpus : QuotaCpus();
+  // The workers spin at the step's barrier, so each is a core: two fewer than a container's CPU quota is worth leave
+  // the runtime's own threads their share (with workers = quota the group was throttled a dozen periods per run,
+  // profiles/r04_exp_decode_workers.txt; 8 .. 14 workers do the same within a few per cent)
+  int W = opt.max_cpus > 0 ? opt.max_cpus : (QuotaCpus() > 3 ? QuotaCpus() - 2 : QuotaCpus());
   if (W <= 0) W = (int)std::thread::hardware_concurrency();
   if (W <= 0) W = 1;
   if (W > S) W = S;
