@@ -21,6 +21,7 @@
 
 #include "gmx_internal.h"
 #include "gmx_math.h"
+#include "gmx_step_dev.h"
 
 // Loads of the block pipeline are issued from inline asm: left to itself hipcc sinks them next to
 // their uses, which puts one memory latency back into every bit.
@@ -656,11 +657,17 @@ extern "C" hipError_t gmx_launch_indirect_init(uint8_t* banks, uint64_t bank_byt
 // stream sits the step out.  Between launches a model keeps {table index, entry, "a forward waits for its learn"} in
 // `latch`; logits and slot values are read and written in the bank itself (two logits per model and bit: no LDS copy
 // of the 82 KiB of tables for one bit's work).  Predictions go straight into the mixers' records of the same step.
+// WITH_LSTM: the LSTM's bit prediction of the same step (gmx_step_dev.h) first, in the same launch -- a launch of its
+// own cost the step 4.5 us for 0.5 us of work; lstm_prediction_context reaches the model that reads it through LDS.
+template <bool WITH_LSTM>
 __global__ void __launch_bounds__(64)
-gmx_indirect_step_kernel(const GmxIndDev* __restrict__ dv, const GmxIndStepArgs a) {
+gmx_indirect_step_kernel(const GmxIndDev* __restrict__ dv, const GmxIndStepArgs a, const GmxLstmDev* __restrict__ ldv,
+                         const GmxLstmBitArgs la) {
   __shared__ uint64_t s_tab[32];
   __shared__ uint8_t nsn[512], rmn[512];
   __shared__ uint32_t mwl[8];
+  __shared__ __attribute__((aligned(16))) float pr[WITH_LSTM ? GMX_L_NO : 4];
+  __shared__ uint32_t lstm_ctx_lds[2];
   const int lane = threadIdx.x;
   const int s = blockIdx.x;
   const uint32_t what = a.what[s];
@@ -673,6 +680,15 @@ gmx_indirect_step_kernel(const GmxIndDev* __restrict__ dv, const GmxIndStepArgs 
   }
   if (lane < 8) mwl[lane] = 0;
   __syncthreads();
+  if (WITH_LSTM && (what & 2u)) {
+    uint32_t c, act;
+    gmx_lstm_bitstep_body(ldv, la, s, what, pr, lane, /*mask_to_global=*/false, c, act);
+    if (lane == 0) {
+      lstm_ctx_lds[0] = c;
+      if (act) atomicOr(&mwl[la.slot >> 5], 1u << (la.slot & 31));  // (the host left the slot's bit clear)
+    }
+    __syncthreads();
+  }
   const bool on = lane < K;
   uint8_t* const bank = a.banks + (uint64_t)s * dv->bank_bytes;
   uint32_t* const L = a.latch + ((uint64_t)s * 64 + lane) * 4;  // {index, entry, have, -}
@@ -691,7 +707,8 @@ gmx_indirect_step_kernel(const GmxIndDev* __restrict__ dv, const GmxIndStepArgs 
     const bool do_learn = (what & 1u) && have;
     const bool do_pred = (what & 2u) != 0;
     const int bit = a.bits[s] ? 1 : 0;
-    const uint32_t ctx = do_pred ? a.ctx[(uint64_t)s * K + lane] : 0u;
+    uint32_t ctx = do_pred ? a.ctx[(uint64_t)s * K + lane] : 0u;
+    if (WITH_LSTM && do_pred && lane == la.ind_ctx_col) ctx = lstm_ctx_lds[0];  // (this launch's own store, not yet re-read)
     const uint32_t bcu = do_pred ? a.bc[s] : 0u;
     float va = slots[2 * lane], vb = slots[2 * lane + 1];
     // ---- trip 2
@@ -759,6 +776,16 @@ gmx_indirect_step_kernel(const GmxIndDev* __restrict__ dv, const GmxIndStepArgs 
 extern "C" hipError_t gmx_launch_indirect_step(const GmxIndDev* dv, const GmxIndStepArgs* args, int n_streams,
                                                hipStream_t stream) {
   (void)hipGetLastError();
-  hipLaunchKernelGGL(gmx_indirect_step_kernel, dim3(n_streams), dim3(64), 0, stream, dv, *args);
+  GmxLstmBitArgs none;
+  memset(&none, 0, sizeof none);
+  hipLaunchKernelGGL(gmx_indirect_step_kernel<false>, dim3(n_streams), dim3(64), 0, stream, dv, *args,
+                     (const GmxLstmDev*)nullptr, none);
+  return hipGetLastError();
+}
+// ... with the LSTM's bit prediction of the same step in front
+extern "C" hipError_t gmx_launch_models_step(const GmxIndDev* dv, const GmxIndStepArgs* args, const GmxLstmDev* ldv,
+                                             const GmxLstmBitArgs* largs, int n_streams, hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gmx_indirect_step_kernel<true>, dim3(n_streams), dim3(64), 0, stream, dv, *args, ldv, *largs);
   return hipGetLastError();
 }

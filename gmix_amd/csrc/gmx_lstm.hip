@@ -30,6 +30,7 @@
 
 #include "gmx_internal.h"
 #include "gmx_math.h"
+#include "gmx_step_dev.h"
 
 // Loads a chain issues before its adds (GMX_LSTM_STRETCH weights, GMX_LSTM_Q float4s) against
 // workgroups per CU (GMX_LSTM_BLOCKS): shorter stretches cost latency per byte, fewer registers
@@ -863,68 +864,11 @@ extern "C" hipError_t gmx_launch_lstm_scatter(const GmxLstmScatterArgs* args, in
 __global__ void __launch_bounds__(64)
 gmx_lstm_bitstep_kernel(const GmxLstmDev* __restrict__ dvp, const GmxLstmBitArgs a) {
   __shared__ __attribute__((aligned(16))) float pr[GMX_L_NO];
-  const int s = blockIdx.x, lane = threadIdx.x;
+  const int s = blockIdx.x;
   const uint32_t what = a.what[s];
   if (!(what & 2u)) return;
-  float* const B = a.banks + (uint64_t)s * dvp->bank_floats;
-  uint32_t* const scal = (uint32_t*)(B + dvp->scal);
-  const float4 q = ((const float4*)(B + dvp->probs))[lane];
-  ((float4*)pr)[lane] = q;
-  __syncthreads();
-  if (lane != 0) return;
-  int top, bot;
-  if (what & 4u) {
-    top = 255;
-    bot = 0;
-  } else {
-    top = (int)scal[8];
-    bot = (int)scal[9];
-    const int mid_before = bot + ((top - bot) / 2);
-    if (a.bits[s])
-      bot = mid_before + 1;
-    else
-      top = mid_before;
-  }
-  const int mid = bot + ((top - bot) / 2);
-  // std::accumulate from the first element up, over the upper half, then on over the lower half.  The halves are
-  // powers of two long and aligned to their length: sixteen values are fetched at a time, added one after the other
-  // (the adds wait for their batch, not each for its own read).
-  auto ordered = [&](float acc, int lo, int n) {
-    int i = lo;
-    for (; n >= 16; n -= 16, i += 16) {
-      const float4 q0 = *(const float4*)(pr + i), q1 = *(const float4*)(pr + i + 4), q2 = *(const float4*)(pr + i + 8),
-                   q3 = *(const float4*)(pr + i + 12);
-      acc += q0.x; acc += q0.y; acc += q0.z; acc += q0.w;
-      acc += q1.x; acc += q1.y; acc += q1.z; acc += q1.w;
-      acc += q2.x; acc += q2.y; acc += q2.z; acc += q2.w;
-      acc += q3.x; acc += q3.y; acc += q3.z; acc += q3.w;
-    }
-    for (; n >= 4; n -= 4, i += 4) {
-      const float4 q = *(const float4*)(pr + i);
-      acc += q.x; acc += q.y; acc += q.z; acc += q.w;
-    }
-    for (; n > 0; --n, ++i) acc += pr[i];
-    return acc;
-  };
-  const float num = ordered(0.0f, mid + 1, top - mid);
-  const float denom = ordered(num, bot, mid - bot + 1);
-  float prediction = __uint_as_float(scal[5]);
-  bool active = false;
-  if (denom != 0.0f) {  // (a silent bit leaves the slot as it was)
-    const float p = num / denom;
-    prediction = gmx_logit(p);
-    active = p != 0.5f;
-    scal[5] = __float_as_uint(prediction);
-  }
-  scal[8] = (uint32_t)top;
-  scal[9] = (uint32_t)bot;
-  a.mx_pred[(uint64_t)s * a.mx_n_pad + a.slot] = prediction;
-  uint32_t* const w = a.mx_mask + (uint64_t)s * a.mx_mask_words + (a.slot >> 5);
-  const uint32_t m = 1u << (a.slot & 31);
-  *w = active ? (*w | m) : (*w & ~m);
-  const uint32_t c = scal[4];
-  if (a.mixer_ctx_col >= 0) a.mx_ctx[(uint64_t)s * a.mx_m + a.mixer_ctx_col] = c;
-  if (a.ind_ctx && a.ind_ctx_col >= 0) a.ind_ctx[(uint64_t)s * a.ind_k + a.ind_ctx_col] = c;
+  uint32_t ctx_unused, mask_bit_unused;
+  gmx_lstm_bitstep_body(dvp, a, s, what, pr, (int)threadIdx.x, /*mask_to_global=*/true, ctx_unused, mask_bit_unused);
 }
 
 extern "C" hipError_t gmx_launch_lstm_bitstep(const GmxLstmDev* dv, const GmxLstmBitArgs* args, int n_streams,
