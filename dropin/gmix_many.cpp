@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <filesystem>
 #include <fstream>
 #include <string>
@@ -86,5 +87,9 @@ int main(int argc, char** argv) {
          in_bytes, out_bytes, st.wall_seconds > 0 ? 8.0 * in_bytes / st.wall_seconds : 0.0,
          st.total_seconds > 0 ? 8.0 * in_bytes / st.total_seconds : 0.0);
   fflush(stdout);
-  return failed ? 1 : 0;
+  fflush(stderr);
+  // Every output file is closed and the line is out: the process ends HERE, without the destructors of 64 Predictors
+  // (2 GB of address space each), of the pool (tens of gigabytes of device memory handed back piece by piece) and of the
+  // runtime -- a second and a half for 64 files, which the kernel does in a fraction when the process just ends.
+  _exit(failed ? 1 : 0);
 }

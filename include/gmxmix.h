@@ -174,8 +174,11 @@ int gmx_group_run(gmx_group* g, gmx_batch* b, uint64_t n_bits, int learn, float*
 
 /* The same for streams that stand at different lengths -- S files compressed side by side
  * (runner-utils.cpp:43-67 once per file) end at different bits: stream s runs bits [0, n_bits[s]) of its
- * records, 0 = the stream sits this launch out.  Neighbouring streams with equal counts share a launch.
- * Asynchronous on the group's stream. */
+ * records, 0 = the stream sits this launch out.  The kernels with one stream per block (the reference's own shape and
+ * the general kernel) take the counts as a per-block list: ONE launch whatever the lengths; the one-mixer and lane-pair
+ * shapes, which put several streams into a wave, run one launch per stretch of neighbouring streams with equal counts
+ * (GMX_RAGGED_SPLIT=1 in the environment forces that for every shape: a debugging aid).  The decay tables of the launch
+ * are staged at a pitch of max(n_bits) for every stream.  Asynchronous on the group's stream. */
 int gmx_group_run_ragged(gmx_group* g, gmx_batch* b, const uint64_t* n_bits /* [S] */, int learn);
 
 /* ---- persistence ------------------------------------------ */

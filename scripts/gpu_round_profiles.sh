@@ -35,10 +35,10 @@ timeout -k 10 300 python3 scripts/bench_pipeline.py > gpurun_out/pipeline_bench.
 fi
 if [[ $PART == *c* ]]; then
 # end to end: one file through every build, many files side by side, the kernel timeline
-bash scripts/e2e_batched.sh 100000 gpurun_out/e2e.txt > /dev/null 2>&1
-EXES=gmix_chain_many bash scripts/exp_cpus.sh "-1" "1 16 64 128" > gpurun_out/many_chain.txt 2>&1
-bash scripts/many_scaling.sh "16 64" 30000 gpurun_out/many_scaling.txt > /dev/null 2>&1
-bash scripts/trace_chain_timeline.sh 30000 2048 1 > gpurun_out/timeline_S1.txt 2>&1
-bash scripts/trace_chain_timeline.sh 30000 2048 64 > gpurun_out/timeline_S64.txt 2>&1
+timeout -k 10 400 bash scripts/e2e_batched.sh 100000 gpurun_out/e2e.txt > /dev/null 2>&1
+EXES=gmix_chain_many timeout -k 10 300 bash scripts/exp_cpus.sh "-1" "1 16 64 128" > gpurun_out/many_chain.txt 2>&1
+timeout -k 10 300 bash scripts/many_scaling.sh "16 64" 30000 gpurun_out/many_scaling.txt > /dev/null 2>&1
+timeout -k 10 200 bash scripts/trace_chain_timeline.sh 30000 2048 1 > gpurun_out/timeline_S1.txt 2>&1
+timeout -k 10 200 bash scripts/trace_chain_timeline.sh 30000 2048 64 > gpurun_out/timeline_S64.txt 2>&1
 fi
 echo done
