@@ -338,7 +338,10 @@ def main():
     ap.add_argument("--only-also", default="", help="comma-separated: of the also{} entries, only these")
     ap.add_argument("--e2e-bytes", type=int, default=30000, help="bytes of the one file of also.e2e_S1 / e2e_S1_mixers")
     ap.add_argument("--e2e-many-bytes", type=int, default=100000, help="bytes per file of also.e2e_S64")
-    ap.add_argument("--decode-bytes", type=int, default=6000, help="bytes per file of also.e2e_decode")
+    ap.add_argument("--also-streams-div", type=int, default=1,
+                    help="divide the stream counts of the also{} kernel entries by this (a test run: dense banks of a "
+                         "thousand streams take seconds to allocate and clear)")
+    ap.add_argument("--decode-bytes", type=int, default=5000, help="bytes per file of also.e2e_decode")
     ap.add_argument("--decode-streams", type=int, default=256, help="files of also.e2e_decode")
     ap.add_argument("--rehearse-cpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-sample-bits", type=int, default=None,
@@ -409,7 +412,9 @@ def main():
                 continue
             try:
                 # warm-up launches: the library's staging slots (decay tables) are allocated by the first of them
+                div = max(1, args.also_streams_div)
                 r = run_workload(name, comm, local_rank, warmup=2, ring_n=2,
+                                 streams=max(1, WORKLOADS[name][2] // div) if div > 1 else None,
                                  want_cpu=not args.no_cpu_baseline and name != "stock_S1")
             except Exception as e:  # a sub-result must never cost the headline line
                 if dist is not None:

@@ -18,7 +18,7 @@ def test_bench_line_carries_the_contract(gpu):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--streams", "1024", "--bits", "256", "--steps", "4",
                         "--cpu-sample-bits", "100000", "--e2e-bytes", "3000", "--e2e-many-bytes", "3000", "--decode-bytes", "300",
-                        "--decode-streams", "8"],
+                        "--decode-streams", "8", "--also-streams-div", "4"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
