@@ -3,7 +3,7 @@
 // Linked by dropin/Makefile against the reference's own translation units (feature models, coder,
 // runner-utils) with Predictor::AddMixers constructing gmx::GpuMixer -- the reference calls the product.
 //
-// usage: gmix_many [-d] [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--device d] <out dir> <input file>...
+// usage: gmix_many [-d] [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--groups g] [--device d] <out dir> <input file>...
 //   each input is compressed to <out dir>/<index>.gmix exactly as `gmix -c` would (runner-utils.cpp:88-121);
 //   -n limits every input to its first n bytes (written to <out dir>/<index>.in first).
 //   -d: each input is a file `gmix -c` wrote and is restored to <out dir>/<index>.out as `gmix -d` would
@@ -39,11 +39,13 @@ int main(int argc, char** argv) {
       opt.max_cpus = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--device") && a + 1 < argc)
       opt.device = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--groups") && a + 1 < argc)
+      opt.groups = atoi(argv[++a]);
     else
       break;
   }
   if (argc - a < 2) {
-    fprintf(stderr, "usage: %s [-d] [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--device d] <out dir> <input file>...\n", argv[0]);
+    fprintf(stderr, "usage: %s [-d] [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--groups g] [--device d] <out dir> <input file>...\n", argv[0]);
     return 2;
   }
   const std::string out_dir = argv[a++];

@@ -63,6 +63,11 @@ struct BatchedOptions {
   bool progress = true;        // runner-utils.cpp:59-63
   int device = -1;             // BatchedCompressFiles: the pool's device (-1: $GMX_DEVICE, else 0) -- one process per GPU
   bool pin_threads = true;     // BatchedCompressFiles: threads onto the cores of the device's NUMA node
+  int groups = 1;              // BatchedDecompressFiles: the files go in this many groups, each a pool, worker threads and a
+                               // lock step of its own, meant to run one group's device step beside the others' host
+                               // turns.  It loses: 256 files 2.8e6 bits/s as one group, 1.9e6 as two or three
+                               // (profiles/r04_exp_decode_groups.txt) -- the groups' graphs take turns on the device and
+                               // each has half the workers.  Kept as an option (tested), off by default
   bool destroy_predictors = true;  // BatchedCompressFiles / BatchedDecompressFiles: false = leave the Predictors standing when
                                // the call returns -- for a command-line driver that exits next: 64 destructors give back
                                // 64 x 2 GB of address space page table by page table (1.8 s for 64 files), the kernel
@@ -121,7 +126,7 @@ inline int QuotaCpus() {
 // max_cpus of them when that is given: a window of the node's list (which names one hardware thread of every core
 // before the second) that starts device * max_cpus in, so that processes driving other devices of the same node take
 // other cores.  No-op when sysfs does not say.
-inline bool PinThreadToDeviceNode(int device, int max_cpus = 0) {
+inline bool PinThreadToDeviceNode(int device, int max_cpus = 0, int window = -1) {
   const std::vector<int> cpus = DeviceNodeCpus(device);
   if (cpus.empty()) return false;
   cpu_set_t now, want;
@@ -133,7 +138,8 @@ inline bool PinThreadToDeviceNode(int device, int max_cpus = 0) {
     if (c < CPU_SETSIZE && CPU_ISSET(c, &now)) allowed.push_back(c);
   if (allowed.empty()) return false;
   const size_t n = allowed.size(), k = (max_cpus <= 0 || (size_t)max_cpus > n) ? n : (size_t)max_cpus;
-  const size_t first = ((size_t)(device < 0 ? 0 : device) * k) % n;
+  // (window >= 0: the window-th stretch of k cores instead of the device's -- several groups of threads of one process)
+  const size_t first = ((size_t)(window >= 0 ? window : (device < 0 ? 0 : device)) * k) % n;
   for (size_t i = 0; i < k; ++i) CPU_SET(allowed[(first + i) % n], &want);
   return sched_setaffinity(0, sizeof want, &want) == 0;
 }
@@ -748,41 +754,56 @@ inline int LockstepDecompress(unsigned long long output_length, std::ifstream* i
   return rc ? rc : bank->status();
 }
 
-// runner_utils::RunDecompression (runner-utils.cpp:123-156) for every job at once: a Predictor and a Decoder per file,
-// all device-side models of all of them one device step per coded bit.  opt.max_cpus worker threads (default: the
-// container's CPU quota, else the hardware's threads, at most one per file) carry the files' fibres.  Returns the
-// number of jobs that failed.
-inline int BatchedDecompressFiles(std::vector<BatchedJob>& jobs, const BatchedOptions& opt_in = BatchedOptions(),
-                                  BatchedStats* stats = nullptr) {
+// What the groups of one BatchedDecompressFiles call share: constructions that draw from rand() (the host's own
+// LstmModel, lstm-layer.h:41) happen one at a time ACROSS groups, and no group brings up the device before every group's
+// Predictors stand (cf. RunManyFiles).
+struct DecompressSync {
+  std::mutex first_mu, serial_mu, mu;
+  std::mutex device_mu;  // one group at a time brings up its banks: a chainstep is CAPTURED into graphs on its group's
+                         // (blocking) stream, and any synchronous copy of another thread meanwhile -- the runtime's legacy
+                         // stream -- "would make the legacy stream depend on a capturing blocking stream" and fails both
+  std::condition_variable cv;
+  int groups = 1, constructed = 0;
+  bool serial = false;
+  void GroupConstructed() {
+    std::unique_lock<std::mutex> lk(mu);
+    ++constructed;
+    cv.notify_all();
+    if (serial) cv.wait(lk, [&] { return constructed >= groups; });
+  }
+};
+struct DecompressGroupResult {
+  std::chrono::steady_clock::time_point t_first, t0, t1;
+  uint64_t steps = 0;
+  int pinned = 0, workers = 0, pool_status = 0;
+  bool parallel_construction = false;
+  std::string error;
+};
+
+// One group: S files, one pool, W worker threads, window-th stretch of W cores of the device's node.
+inline void DecompressGroup(BatchedJob* jobs, int S, int W, int window, const BatchedOptions& opt, DecompressSync* sync,
+                            DecompressGroupResult* res) {
   using clock = std::chrono::steady_clock;
-  const clock::time_point tb = clock::now();
-  BatchedOptions opt = opt_in;
-  const int S = (int)jobs.size();
-  if (S == 0) return 0;
-  // The workers spin at the step's barrier, so each is a core: two fewer than a container's CPU quota is worth leave
-  // the runtime's own threads their share (with workers = quota the group was throttled a dozen periods per run,
-  // profiles/r04_exp_decode_workers.txt; 8 .. 14 workers do the same within a few per cent)
-  int W = opt.max_cpus > 0 ? opt.max_cpus : (QuotaCpus() > 3 ? QuotaCpus() - 2 : QuotaCpus());
-  if (W <= 0) W = (int)std::thread::hardware_concurrency();
-  if (W <= 0) W = 1;
-  if (W > S) W = S;
   MixerPool pool(S, opt.device);
-  pool.Install();
+  {
+    std::lock_guard<std::mutex> lk(sync->serial_mu);  // (the draw IS rand(): not beside a constructor that draws)
+    pool.DrawLstmInit();
+  }
   std::vector<std::ifstream> in(S);
   std::vector<std::ofstream> out(S);
   std::vector<std::unique_ptr<Predictor>> preds(S);
-  std::mutex construct, first_mu;
+  std::mutex first_mu;
   std::condition_variable first_cv;
   bool first_built = false;
   std::atomic<int> pinned{0};
-  clock::time_point t_first = tb, t0 = tb, t1 = tb;
+  res->t_first = res->t0 = res->t1 = clock::now();
   LockstepRunner runner(&pool, W);
   pool.SetLockstepYield([](int) { LockstepRunner::Yield(); });
   std::vector<char> worker_pinned(W, 0);
   auto pin = [&](int w) {
     if (worker_pinned[w]) return;
     worker_pinned[w] = 1;
-    if (opt.pin_threads && PinThreadToDeviceNode(pool.device(), W)) ++pinned;
+    if (opt.pin_threads && PinThreadToDeviceNode(pool.device(), W, window)) ++pinned;
   };
   // A fibre runs the reference's Decoder and nothing that calls the device: the banks are brought up and joined
   // (BeginLockstep) on the worker threads' own stacks before the fibres start, every step is taken there too, and a
@@ -808,7 +829,9 @@ inline int BatchedDecompressFiles(std::vector<BatchedJob>& jobs, const BatchedOp
       out[s].close();
     });
   }
+  std::atomic<int> setups_left{W};
   auto setup = [&](int w) {
+    pool.InstallForThisThread();  // this thread's Predictors are this group's pool's
     for (int s = w; s < S; s += W) {
       BatchedJob& job = jobs[s];
       in[s].open(job.input_path, std::ios::in | std::ios::binary);
@@ -822,12 +845,21 @@ inline int BatchedDecompressFiles(std::vector<BatchedJob>& jobs, const BatchedOp
         ok = out[s].is_open();
       }
       if (!ok) job.status = -100;
-      // (construction as in RunManyFiles: the first Predictor alone, the others side by side when no constructor draws)
+      // (construction as in RunManyFiles: the first Predictor alone -- alone among ALL groups --, the others side by side
+      // when no constructor draws, else one at a time across the groups)
       if (s == 0) {
-        if (ok) preds[0].reset(new Predictor());
+        {
+          std::lock_guard<std::mutex> one(sync->first_mu);
+          std::lock_guard<std::mutex> two(sync->serial_mu);  // (another group's later Predictors may be drawing)
+          if (ok) preds[0].reset(new Predictor());
+          if (!pool.parallel_construction()) {
+            std::lock_guard<std::mutex> lk(sync->mu);
+            sync->serial = true;
+          }
+        }
         std::lock_guard<std::mutex> lk(first_mu);
         first_built = true;
-        t_first = clock::now();
+        res->t_first = clock::now();
         first_cv.notify_all();
         continue;
       }
@@ -840,14 +872,16 @@ inline int BatchedDecompressFiles(std::vector<BatchedJob>& jobs, const BatchedOp
         pin(w);
         preds[s].reset(new Predictor());
       } else {
-        std::lock_guard<std::mutex> lk(construct);
+        std::lock_guard<std::mutex> lk(sync->serial_mu);
         preds[s].reset(new Predictor());
       }
     }
+    if (setups_left.fetch_sub(1) == 1) sync->GroupConstructed();  // (the group's last worker; waits for the others if serial)
   };
   // ... and, every Predictor standing: the device banks (the first to get here creates them for all), each stream's join
   auto join = [&](int w) {
     pin(w);  // (where constructors draw from rand() the threads are only pinned now)
+    std::lock_guard<std::mutex> one_group(sync->device_mu);
     for (int s = w; s < S; s += W) {
       if (!preds[s] || jobs[s].status) continue;
       banks[s] = GpuMixerBank::Of(preds[s].get(), sizeof(Predictor));
@@ -861,36 +895,83 @@ inline int BatchedDecompressFiles(std::vector<BatchedJob>& jobs, const BatchedOp
     }
   };
   bool started = false;
-  const uint64_t steps = runner.Run(setup, join, [&] {
+  res->steps = runner.Run(setup, join, [&] {
     if (!started) {
       started = true;
-      t0 = clock::now();  // (the first step: every fibre has built nothing more than its first record)
+      res->t0 = clock::now();  // (the first step: every fibre has built nothing more than its first record)
     }
     return pool.StepAll();
   });
-  t1 = clock::now();
+  res->t1 = clock::now();
   pool.SetLockstepYield(nullptr);
   if (opt.destroy_predictors) {
     preds.clear();
   } else {
     for (auto& p : preds) p.release();
   }
-  pool.Uninstall();
+  res->pinned = pinned.load();
+  res->workers = W;
+  res->parallel_construction = pool.parallel_construction();
+  res->pool_status = pool.status();
+  if (res->pool_status) res->error = pool.error();
+}
+
+// runner_utils::RunDecompression (runner-utils.cpp:123-156) for every job at once: a Predictor and a Decoder per file,
+// all device-side models of a group of them one device step per coded bit.  opt.max_cpus worker threads in all
+// (default: two fewer than the container's CPU quota is worth, else the hardware's threads) carry the files' fibres;
+// opt.groups groups (default one) each have a pool, their share of the workers and a lock step of their own.  Returns the
+// number of jobs that failed.
+inline int BatchedDecompressFiles(std::vector<BatchedJob>& jobs, const BatchedOptions& opt_in = BatchedOptions(),
+                                  BatchedStats* stats = nullptr) {
+  using clock = std::chrono::steady_clock;
+  const clock::time_point tb = clock::now();
+  BatchedOptions opt = opt_in;
+  const int S = (int)jobs.size();
+  if (S == 0) return 0;
+  // The workers spin at the step's barrier, so each is a core: two fewer than a container's CPU quota is worth leave
+  // the runtime's own threads their share (with workers = quota the group was throttled a dozen periods per run,
+  // profiles/r04_exp_decode_workers.txt; 8 .. 14 workers do the same within a few per cent)
+  int W = opt.max_cpus > 0 ? opt.max_cpus : (QuotaCpus() > 3 ? QuotaCpus() - 2 : QuotaCpus());
+  if (W <= 0) W = (int)std::thread::hardware_concurrency();
+  if (W <= 0) W = 1;
+  if (W > S) W = S;
+  int G = opt.groups > 0 ? opt.groups : 1;
+  if (G > W) G = W;
+  if (G > S) G = S;
+  DecompressSync sync;
+  sync.groups = G;
+  std::vector<DecompressGroupResult> res(G);
+  std::vector<std::thread> threads;
+  for (int g = 0; g < G; ++g) {
+    const int s0 = (int)((long long)S * g / G), s1 = (int)((long long)S * (g + 1) / G);
+    const int w0 = (int)((long long)W * g / G), w1 = (int)((long long)W * (g + 1) / G);
+    threads.emplace_back([&, g, s0, s1, w0, w1] {
+      DecompressGroup(jobs.data() + s0, s1 - s0, std::max(1, std::min(w1 - w0, s1 - s0)), G > 1 ? g : -1, opt, &sync, &res[g]);
+    });
+  }
+  for (auto& t : threads) t.join();
   int failed = 0;
   for (auto& j : jobs) failed += j.status != 0;
-  if (pool.status() != 0) fprintf(stderr, "gmx::BatchedDecompressFiles: %s\n", pool.error().c_str());
+  for (auto& r : res)
+    if (r.pool_status != 0) fprintf(stderr, "gmx::BatchedDecompressFiles: %s\n", r.error.c_str());
   if (stats) {
     const clock::time_point tz = clock::now();
+    clock::time_point t0 = res[0].t0, t1 = res[0].t1, tf = res[0].t_first;
+    for (auto& r : res) {
+      t0 = std::min(t0, r.t0);
+      t1 = std::max(t1, r.t1);
+      tf = std::min(tf, r.t_first);
+      stats->launches += r.steps;
+      stats->pinned_threads += r.pinned;
+      stats->pinned_cpus += r.workers;
+    }
     stats->total_seconds = std::chrono::duration<double>(tz - tb).count();
     stats->wall_seconds = std::chrono::duration<double>(t1 - t0).count();
     stats->build_seconds = std::chrono::duration<double>(t0 - tb).count();
-    stats->first_predictor_seconds = std::chrono::duration<double>(t_first - tb).count();
+    stats->first_predictor_seconds = std::chrono::duration<double>(tf - tb).count();
     stats->teardown_seconds = std::chrono::duration<double>(tz - t1).count();
-    stats->parallel_construction = pool.parallel_construction();
-    stats->launches = steps;
+    stats->parallel_construction = res[0].parallel_construction;
     for (auto& j : jobs) stats->bits += 8ull * j.output_bytes;
-    stats->pinned_threads = pinned.load();
-    stats->pinned_cpus = W;
   }
   return failed;
 }

@@ -157,6 +157,25 @@ class MixerPool {
     static MixerPool* p = nullptr;
     return p;
   }
+  // A thread may name the pool ITS Predictors go to (InstallForThisThread; nullptr: the process-wide one again): several
+  // pools side by side, each with worker threads of its own (gmx::BatchedDecompressFiles' groups).
+  static MixerPool*& ThreadPool() {
+    static thread_local MixerPool* p = nullptr;
+    return p;
+  }
+  static MixerPool* Current() {  // AdapterMutex() held
+    MixerPool* t = ThreadPool();
+    return t ? t : Installed();
+  }
+  void InstallForThisThread() {
+    {
+      std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
+      shared_ = true;
+      DrawLstmInit();
+    }
+    ThreadPool() = this;
+  }
+  static void UninstallForThisThread() { ThreadPool() = nullptr; }
   // From now on the banks of every Predictor constructed (on any thread) live in this pool.  The pool must
   // outlive them.
   void Install() {
@@ -180,7 +199,8 @@ class MixerPool {
   // constructions stay serial, drawing for themselves as before.
   static constexpr int kLstmDraws = 3 * 50 * 563;
   void DrawLstmInit() {
-    if (!lstm_init_.empty()) return;
+    if (!lstm_init_.empty() || lstm_init_tried_) return;
+    lstm_init_tried_ = true;
     std::vector<int> draws(kLstmDraws);
     for (int attempt = 0; attempt < 3; ++attempt) {
       srand(0xDEADBEEF);
@@ -280,7 +300,7 @@ class MixerPool {
     auto it = priv.find(ltm);
     if (it != priv.end()) sp = it->second.lock();
     if (!sp) {
-      if (MixerPool* inst = Installed()) {
+      if (MixerPool* inst = Current()) {
         sp = std::shared_ptr<MixerPool>(inst, [](MixerPool*) {});
       } else {
         sp.reset(new MixerPool(1));
@@ -651,6 +671,7 @@ class MixerPool {
   std::function<void(int)> yield_;
   static constexpr uint64_t kLstmDrawsFnv = 0xcb25b734d7bec78full;  // FNV-1a over the draws (glibc's rand(): TYPE_3, r[i] = r[i-3] + r[i-31])
   std::vector<int> lstm_init_;
+  bool lstm_init_tried_ = false;
   std::atomic<bool> lstm_from_cache_{false};
   gmx_group* group_ = nullptr;
   gmx_indirect* ind_ = nullptr;
@@ -1456,7 +1477,7 @@ class GpuLstmModel : public Model {
     const int* drawn = nullptr;
     {
       std::lock_guard<std::recursive_mutex> lk(AdapterMutex());
-      if (MixerPool* inst = MixerPool::Installed()) {
+      if (MixerPool* inst = MixerPool::Current()) {
         drawn = inst->lstm_init();
         if (drawn) inst->lstm_from_cache_.store(true);
       }

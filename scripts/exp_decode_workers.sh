@@ -13,9 +13,9 @@ for S in $LIST; do
   C=$(for i in $(seq 0 $((S-1))); do echo $W/c/$i.gmix; done)
   for w in $WS; do
     a=$(grep -E "nr_throttled" /sys/fs/cgroup/cpu.stat | cut -d' ' -f2)
-    dropin/_build/gmix_chain_many -d --cpus $w $W/b $C > $W/j.json 2> $W/err
+    dropin/_build/gmix_chain_many -d --cpus $w --groups ${GROUPS_N:-1} $W/b $C > $W/j.json 2> $W/err
     b=$(grep -E "nr_throttled" /sys/fs/cgroup/cpu.stat | cut -d' ' -f2)
-    python3 -c "import json;j=json.load(open('$W/j.json'));print('S=%d workers=%d: %.1f us/step, %.3g bits/s in the loops, throttled periods %d' % (j['files'], j['pinned_cpus'], j['wall_seconds']*1e6/j['launches'], j['bits_per_second'], $b-$a))"
+    python3 -c "import json;j=json.load(open('$W/j.json'));print('S=%d workers=%d groups=${GROUPS_N:-1}: %.1f us/step (steps of all groups counted), %.3g bits/s in the loops, throttled periods %d' % (j['files'], j['pinned_cpus'], j['wall_seconds']*1e6/j['launches'], j['bits_per_second'], $b-$a))"
   done
 done
 rm -rf $W

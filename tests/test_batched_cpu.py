@@ -96,12 +96,16 @@ def test_predictors_built_side_by_side_where_no_constructor_draws(tmp_path, exe,
         assert (tmp_path / f"ref{k}").read_bytes() == (tmp_path / "out" / f"{k}.gmix").read_bytes(), f"file {k}"
 
 
-@pytest.mark.parametrize("exe,cpus", [("gmix_many_shim", 2), ("gmix_chain_many_shim", 3), ("gmix_chain_many_shim", 1)])
-def test_many_files_restored_in_lock_step(tmp_path, exe, cpus):
+@pytest.mark.parametrize("exe,cpus,groups", [("gmix_many_shim", 2, 1), ("gmix_chain_many_shim", 3, 1),
+                                             ("gmix_chain_many_shim", 1, 1), ("gmix_chain_many_shim", 4, 2),
+                                             ("gmix_many_shim", 3, 3)])
+def test_many_files_restored_in_lock_step(tmp_path, exe, cpus, groups):
     """gmx::BatchedDecompressFiles: five files the STOCK build compressed (0 / 1 / 613 / 300 / 613 bytes) restored
     together -- the reference's own Decoder per file, each on a fibre, `cpus` worker threads, one gmx_chainstep step per
     coded bit for all of them; files that end early sit the remaining steps out, every file's last Learn is a step
-    without a Predict.  Byte-identical to the inputs."""
+    without a Predict.  `groups` > 1: the files in that many groups, each a pool, workers and a lock step of its own
+    (Predictors that draw from rand() -- the mixers-only build -- still constructed one at a time across the groups).
+    Byte-identical to the inputs."""
     _skip_unless("gmix_strict", exe)
     files, coded = [], []
     for k, n in enumerate((0, 1, 613, 300, 613)):
@@ -110,7 +114,7 @@ def test_many_files_restored_in_lock_step(tmp_path, exe, cpus):
         files.append(f)
         gmix("gmix_strict", "-c", f, tmp_path / f"c{k}", tmp_path)
         coded.append(tmp_path / f"c{k}")
-    st = run_many(exe, coded, tmp_path / "back", 2048, extra=("-d", "--cpus", str(cpus)))
-    assert st["mode"] == "decompress" and st["failed"] == 0 and st["launches"] >= 8 * 613 + 1
+    st = run_many(exe, coded, tmp_path / "back", 2048, extra=("-d", "--cpus", str(cpus), "--groups", str(groups)))
+    assert st["mode"] == "decompress" and st["failed"] == 0 and st["launches"] >= 8 * 613 + 1   # (summed over the groups)
     for k, f in enumerate(files):
         assert (tmp_path / "back" / f"{k}.out").read_bytes() == f.read_bytes(), f"file {k}"
