@@ -361,6 +361,11 @@ class ChainStep:
         padded[:len(active)] = np.asarray(active) != 0
         self.active_mask[stream] = np.packbits(padded.reshape(self.mask_words, 32), axis=1, bitorder="little").view(np.uint32).reshape(-1)
 
+    def commit(self, stream):
+        """Optional: the stream's inputs for the coming step are complete (moved to the device now where the host can
+        store there; step() does it for streams nobody committed)."""
+        check(self.L.gmx_chainstep_commit(self.h, stream), "gmx_chainstep_commit")
+
     def step(self):
         check(self.L.gmx_chainstep_step(self.h), "gmx_chainstep_step")
 

@@ -5,6 +5,7 @@
 
 #include "gmx_internal.h"
 #include "gmx_math.h"
+#include "gmx_step_dev.h"
 
 // ---------------------------------------------------------------------------------------
 // Synthetic record generator (BASELINE.json configs[1]; definition in oracle/gmx_synth.h,
@@ -317,6 +318,16 @@ extern "C" hipError_t gmx_launch_decay_kernel(const GmxDecayArgs* args, hipStrea
 __global__ void __launch_bounds__(256) gmx_copy16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, uint64_t n16) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x)
     dst[i] = src[i];
+}
+// The head of a lock-step step as a launch of its own (chains whose first kernel is not the Indirect models'): block s
+// brings stream s's inputs in.
+__global__ void __launch_bounds__(64) gmx_step_upload_kernel(const GmxStepUpload u) {
+  gmx_step_upload(u, (int)blockIdx.x, (int)threadIdx.x);
+}
+extern "C" hipError_t gmx_launch_step_upload(const GmxStepUpload* u, int n_streams, hipStream_t stream) {
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gmx_step_upload_kernel, dim3(n_streams), dim3(64), 0, stream, *u);
+  return hipGetLastError();
 }
 extern "C" hipError_t gmx_launch_copy16(void* dst, const void* src, uint64_t n16, hipStream_t stream) {
   (void)hipGetLastError();

@@ -670,6 +670,9 @@ gmx_indirect_step_kernel(const GmxIndDev* __restrict__ dv, const GmxIndStepArgs 
   __shared__ uint32_t lstm_ctx_lds[2];
   const int lane = threadIdx.x;
   const int s = blockIdx.x;
+  // (the step's first launch: the stream's control words and records come in from pinned host memory with it -- a copy
+  // kernel in front cost the step 6 us; a.what and everything else below point into the device copy it fills)
+  if (a.up.n > 0) gmx_step_upload(a.up, s, lane);
   const uint32_t what = a.what[s];
   if (!(what & 3u)) return;
   const int K = dv->k;

@@ -158,6 +158,38 @@ struct GmxLsArgs {
 };
 #define GMX_LS_LIVE_FLOATS 160  // pred[96] | mask[4] | ctx[36] | dec | pad
 
+// One step of the lock-step chain for the mixers of the reference's own shape (gmx_stock_step_kernel, gmx_chainstep.inc):
+// Mixer::Learn x 33 on the records of the stream's last forward, then Mixer::Predict x 33 on this step's, in ONE launch.
+struct GmxStkStepArgs {
+  uint8_t* banks;
+  const uint8_t* what;      // [S] bit 0: learn, bit 1: predict; 0: the stream sits the step out
+  const uint8_t* bits;      // [S] the coded bit of each stream's previous forward
+  const float* dec;         // [S] decay factor of the learn
+  const float* pred_old;    // [S][92]  the records the learn works on: the step before's ...
+  const uint32_t* mask_old; // [S][3]
+  const uint32_t* ctx_old;  // [S][33]
+  const float* pred_new;    // ... and this step's
+  const uint32_t* mask_new;
+  const uint32_t* ctx_new;
+  float* p_out;             // [S]     pinned host memory
+  float* out_all;           // [S][33] pinned host memory, or null
+  float* latch;             // [S][33] the outputs a learn-only launch starts from (gmx_group::latch_out)
+  const uint32_t* seq;      // [S] the step's number ...
+  uint32_t* stamp;          // [S] pinned host memory: ... stored here by the stream's block when its answers are out
+  int32_t n_streams, exact;
+};
+
+// The head of a step: every block fetches its own stream's slices of the step's pinned host block (control words and
+// records: arrays of [S][bytes_per_stream]) and stores them at the same offsets of the device copy.
+#define GMX_STEP_UP_MAX 12
+struct GmxStepUpload {
+  const uint8_t* src;       // the host block as the device sees it
+  uint8_t* dst;             // this step's device copy
+  uint32_t off[GMX_STEP_UP_MAX];   // where an array starts in the block
+  uint32_t bps[GMX_STEP_UP_MAX];   // bytes per stream (1 or a multiple of 4)
+  int32_t n;
+};
+
 // ---- Indirect models (models/indirect.cpp) -------------------
 #define GMX_IND_MAX_MODELS 64
 
@@ -241,6 +273,7 @@ struct GmxIndStepArgs {
   int32_t mx_n_pad, mx_mask_words;
   float* pred_out;         // [S][2k] or null (tests)
   uint8_t* act_out;        // [S][2k]
+  GmxStepUpload up;        // up.n > 0: the launch is the step's first -- it brings the stream's inputs in itself
 };
 
 // ---- LSTM byte model (models/lstm*.cpp) -----------------------

@@ -6,6 +6,51 @@
 #include "gmx_internal.h"
 #include "gmx_math.h"
 
+// The head of a step (GmxStepUpload): block s brings stream s's slices of the step's pinned host block into the device
+// copy -- every load in flight before the first store, so the block pays the link's latency once -- and makes them
+// visible to its own later loads.  Called by all 64 threads of a one-wave block.
+__device__ __forceinline__ void gmx_step_upload(const GmxStepUpload& u, int s, int lane) {
+  uint32_t total = 0;  // in units: 4 bytes, or 1 byte for the byte arrays
+  for (int e = 0; e < u.n; ++e) total += (u.bps[e] & 3u) ? u.bps[e] : u.bps[e] >> 2;
+  for (uint32_t base = 0; base < total; base += 256) {
+    uint32_t v[4], at[4];
+    bool word[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      uint32_t i = base + (uint32_t)lane + 64u * (uint32_t)r;
+      at[r] = 0xffffffffu;
+      word[r] = true;
+      v[r] = 0;
+      if (i < total) {
+        for (int e = 0; e < u.n; ++e) {
+          const bool w = !(u.bps[e] & 3u);
+          const uint32_t n = w ? u.bps[e] >> 2 : u.bps[e];
+          if (i < n) {
+            at[r] = u.off[e] + (uint32_t)s * u.bps[e] + (w ? 4u * i : i);
+            word[r] = w;
+            break;
+          }
+          i -= n;
+        }
+        if (word[r])
+          v[r] = *(const uint32_t*)(u.src + at[r]);
+        else
+          v[r] = u.src[at[r]];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (at[r] == 0xffffffffu) continue;
+      if (word[r])
+        *(uint32_t*)(u.dst + at[r]) = v[r];
+      else
+        u.dst[at[r]] = (uint8_t)v[r];
+    }
+  }
+  __threadfence();  // the stores are in L2 and this CU's L1 holds nothing older before anybody reads them back
+  __syncthreads();
+}
+
 // LstmModel::Predict's walk down the byte distribution for ONE bit of stream s (lstm-model.cpp:34-48; see
 // gmx_lstm_bitstep_kernel).  Every thread of the block calls it (`pr`: 256 floats of LDS); the result is lane 0's.
 // ctx_out = lstm_prediction_context; mask_bit_out = whether SetPrediction marked the slot active.  mask_to_global:

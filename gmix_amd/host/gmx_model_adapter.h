@@ -656,6 +656,9 @@ class MixerPool {
   }
   // a stream has recorded what its next step needs: until the step has run
   void LockstepWait(int slot) {
+    // the stream's records for the coming step are complete: into the device now, by this thread (S decoders on a few
+    // worker threads move theirs side by side; what is left for the thread that steps is the control words)
+    (void)gmx_chainstep_commit(cs_, slot);
     if (yield_)
       yield_(slot);
     else

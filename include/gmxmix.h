@@ -427,7 +427,12 @@ int gmx_lstm_memory_usage(gmx_lstm* l, uint64_t* bytes);
  * and calls gmx_chainstep_step, which returns with p[s] (and outputs[s][M]) of the streams that predicted.  A stream
  * whose what[s] is 0 sits the step out (its file has ended) -- but not between a Predict and its Learn: the Learn belongs
  * to the very next step (GMX_ERR_STATE otherwise); streams start at a byte boundary.  One hipGraph of kernels per step;
- * same floats as every other surface.  Destroy before the banks. */
+ * same floats as every other surface.  Destroy before the banks.
+ * gmx_chainstep_commit(cs, s), optional: stream s has filled what[s], bits[s] and its records for the coming step --
+ * where the host can store into device memory the library moves them there right away, in the calling thread (S decoders
+ * on several threads: each commits its own streams, any number of threads at once, before the one that calls
+ * gmx_chainstep_step); streams nobody committed are moved by gmx_chainstep_step itself.  Nothing of stream s may be
+ * written between its commit and the step. */
 #define GMX_STEP_LEARN 1u
 #define GMX_STEP_PREDICT 2u
 typedef struct gmx_chainstep gmx_chainstep;
@@ -445,6 +450,7 @@ uint8_t* gmx_chainstep_bits(gmx_chainstep* cs);          /* [S] */
 uint8_t* gmx_chainstep_what(gmx_chainstep* cs);          /* [S] GMX_STEP_* */
 const float* gmx_chainstep_p(gmx_chainstep* cs);         /* [S] */
 const float* gmx_chainstep_outputs(gmx_chainstep* cs);   /* [S][M] */
+int gmx_chainstep_commit(gmx_chainstep* cs, int stream);
 int gmx_chainstep_step(gmx_chainstep* cs);
 
 /* ==== Compute-unit shares ======================================================================
