@@ -3,12 +3,13 @@
 // Linked by dropin/Makefile against the reference's own translation units (feature models, coder,
 // runner-utils) with Predictor::AddMixers constructing gmx::GpuMixer -- the reference calls the product.
 //
-// usage: gmix_many [-d] [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--groups g] [--device d] <out dir> <input file>...
+// usage: gmix_many [-d] [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--groups g] [--destroy] [--device d] <out dir> <input file>...
 //   each input is compressed to <out dir>/<index>.gmix exactly as `gmix -c` would (runner-utils.cpp:88-121);
 //   -n limits every input to its first n bytes (written to <out dir>/<index>.in first).
 //   -d: each input is a file `gmix -c` wrote and is restored to <out dir>/<index>.out as `gmix -d` would
 //   (runner-utils.cpp:123-156), all files together through gmx::BatchedDecompressFiles (Decoders in lock step).
 //   One JSON line on stdout: per-file sizes and times, the wall time of the compression phase, bits, launches.
+#include <sys/resource.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,11 +42,13 @@ int main(int argc, char** argv) {
       opt.device = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--groups") && a + 1 < argc)
       opt.groups = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--destroy"))
+      opt.destroy_predictors = true;  // (experiments: the Predictors' destructors before the process ends)
     else
       break;
   }
   if (argc - a < 2) {
-    fprintf(stderr, "usage: %s [-d] [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--groups g] [--device d] <out dir> <input file>...\n", argv[0]);
+    fprintf(stderr, "usage: %s [-d] [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--groups g] [--destroy] [--device d] <out dir> <input file>...\n", argv[0]);
     return 2;
   }
   const std::string out_dir = argv[a++];
@@ -85,8 +88,16 @@ int main(int argc, char** argv) {
   for (size_t k = 0; k < jobs.size(); ++k)
     printf("%s{\"in\": %llu, \"out\": %llu, \"status\": %d, \"seconds\": %.6f}", k ? ", " : "", jobs[k].input_bytes,
            jobs[k].output_bytes, jobs[k].status, jobs[k].seconds);
-  printf("], \"input_bytes\": %llu, \"output_bytes\": %llu, \"bits_per_second\": %.1f, \"bits_per_second_cold\": %.1f}\n",
-         in_bytes, out_bytes, st.wall_seconds > 0 ? 8.0 * in_bytes / st.wall_seconds : 0.0,
+  // (what the host gave the process: CPU seconds against wall time, and how often a thread was taken off its core --
+  // on a busy host the lock step's spinning workers wait for whichever of them that happened to)
+  struct rusage ru;
+  memset(&ru, 0, sizeof ru);
+  getrusage(RUSAGE_SELF, &ru);
+  printf("], \"input_bytes\": %llu, \"output_bytes\": %llu, \"cpu_seconds\": %.3f, \"involuntary_switches\": %ld, "
+         "\"bits_per_second\": %.1f, \"bits_per_second_cold\": %.1f}\n",
+         in_bytes, out_bytes,
+         ru.ru_utime.tv_sec + ru.ru_stime.tv_sec + 1e-6 * (ru.ru_utime.tv_usec + ru.ru_stime.tv_usec), ru.ru_nivcsw,
+         st.wall_seconds > 0 ? 8.0 * in_bytes / st.wall_seconds : 0.0,
          st.total_seconds > 0 ? 8.0 * in_bytes / st.total_seconds : 0.0);
   fflush(stdout);
   fflush(stderr);

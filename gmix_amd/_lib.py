@@ -167,6 +167,8 @@ def lib():
     L.gmx_chainstep_n_streams.argtypes = [vp]
     L.gmx_chainstep_step.argtypes = [vp]
     L.gmx_chainstep_commit.argtypes = [vp, i32]
+    L.gmx_chainstep_launch.argtypes = [vp]
+    L.gmx_chainstep_wait.argtypes = [vp]
     for name in ("predictions", "active_mask", "contexts", "ind_contexts", "bit_contexts", "ppm", "bits", "what", "p",
                  "outputs"):
         f = getattr(L, "gmx_chainstep_" + name)
@@ -212,6 +214,6 @@ ABI_SYMBOLS = [
     "gmx_chainstep_create", "gmx_chainstep_destroy", "gmx_chainstep_n_streams", "gmx_chainstep_predictions",
     "gmx_chainstep_active_mask", "gmx_chainstep_contexts", "gmx_chainstep_ind_contexts", "gmx_chainstep_bit_contexts",
     "gmx_chainstep_ppm", "gmx_chainstep_bits", "gmx_chainstep_what", "gmx_chainstep_p", "gmx_chainstep_outputs",
-    "gmx_chainstep_commit", "gmx_chainstep_step",
+    "gmx_chainstep_commit", "gmx_chainstep_step", "gmx_chainstep_launch", "gmx_chainstep_wait",
     "gmx_group_set_cu_mask", "gmx_indirect_set_cu_mask", "gmx_lstm_set_cu_mask",
 ]

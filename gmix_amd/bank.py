@@ -369,6 +369,14 @@ class ChainStep:
     def step(self):
         check(self.L.gmx_chainstep_step(self.h), "gmx_chainstep_step")
 
+    def launch(self):
+        """step() in two halves: queued when this returns ..."""
+        check(self.L.gmx_chainstep_launch(self.h), "gmx_chainstep_launch")
+
+    def wait(self):
+        """... p and outputs in place when this does."""
+        check(self.L.gmx_chainstep_wait(self.h), "gmx_chainstep_wait")
+
     def close(self):
         if getattr(self, "h", None):
             self.L.gmx_chainstep_destroy(self.h)

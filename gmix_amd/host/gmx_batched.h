@@ -38,6 +38,7 @@
 #define GMX_BATCHED_H_
 
 #include <sched.h>
+#include <dirent.h>
 #include <sys/mman.h>
 
 #include <chrono>
@@ -63,11 +64,12 @@ struct BatchedOptions {
   bool progress = true;        // runner-utils.cpp:59-63
   int device = -1;             // BatchedCompressFiles: the pool's device (-1: $GMX_DEVICE, else 0) -- one process per GPU
   bool pin_threads = true;     // BatchedCompressFiles: threads onto the cores of the device's NUMA node
-  int groups = 1;              // BatchedDecompressFiles: the files go in this many groups, each a pool, worker threads and a
-                               // lock step of its own, meant to run one group's device step beside the others' host
-                               // turns.  It loses: 256 files 2.8e6 bits/s as one group, 1.9e6 as two or three
-                               // (profiles/r04_exp_decode_groups.txt) -- the groups' graphs take turns on the device and
-                               // each has half the workers.  Kept as an option (tested), off by default
+  int groups = 1;              // BatchedDecompressFiles: the files go in this many pools, each a lock step of its own, taken in
+                               // turn by the same worker threads (one pool's device step beside the other's host turn).
+                               // A wash, so one by default: a step's device time hardly depends on its stream count (two
+                               // launches of latency chains, 21 us at 64 streams, 27 at 256), so two pools are twice the
+                               // device time per bit of all files for the host time they hide -- 256 files: 3.0-3.4e6
+                               // bits/s either way (profiles/r04_exp_decode_pools.txt).  Kept as an option (tested).
   bool destroy_predictors = true;  // BatchedCompressFiles / BatchedDecompressFiles: false = leave the Predictors standing when
                                // the call returns -- for a command-line driver that exits next: 64 destructors give back
                                // 64 x 2 GB of address space page table by page table (1.8 s for 64 files), the kernel
@@ -106,6 +108,58 @@ inline std::vector<int> DeviceNodeCpus(int device) {
   return cpus;
 }
 
+// Where the device stands among the GPUs of its NUMA node (*rank of *count; both from sysfs: every AMD display /
+// accelerator function with that numa_node, in bus order -- also the ones this process cannot open).  A host with
+// several GPUs per node has a process per GPU, often a container each that calls its own "device 0": the rank is what
+// tells their core windows apart.  false when sysfs does not say.
+inline bool DeviceRankOnNode(int device, int* rank, int* count) {
+  char bus[64] = {0};
+  if (gmx_device_pci_bus_id(device, bus, sizeof bus) != GMX_OK) return false;
+  std::string id(bus);
+  for (auto& ch : id) ch = (char)tolower(ch);
+  int node = -1;
+  {
+    std::ifstream nf("/sys/bus/pci/devices/" + id + "/numa_node");
+    if (!(nf >> node) || node < 0) return false;
+  }
+  std::vector<std::string> gpus;
+  if (DIR* d = opendir("/sys/bus/pci/devices")) {
+    while (struct dirent* e = readdir(d)) {
+      if (e->d_name[0] == '.') continue;
+      const std::string base = std::string("/sys/bus/pci/devices/") + e->d_name;
+      std::string vendor, cls;
+      int n = -1;
+      {
+        std::ifstream f(base + "/vendor");
+        f >> vendor;
+      }
+      if (vendor != "0x1002") continue;
+      {
+        std::ifstream f(base + "/class");
+        f >> cls;  // 0x0300xx VGA, 0x0302xx 3D, 0x0380xx display, 0x1200xx processing accelerator
+      }
+      if (cls.compare(0, 4, "0x03") != 0 && cls.compare(0, 6, "0x1200") != 0) continue;
+      {
+        std::ifstream f(base + "/numa_node");
+        f >> n;
+      }
+      if (n == node) gpus.push_back(e->d_name);
+    }
+    closedir(d);
+  }
+  std::sort(gpus.begin(), gpus.end());
+  for (size_t i = 0; i < gpus.size(); ++i) {
+    std::string g = gpus[i];
+    for (auto& ch : g) ch = (char)tolower(ch);
+    if (g == id) {
+      *rank = (int)i;
+      *count = (int)gpus.size();
+      return true;
+    }
+  }
+  return false;
+}
+
 // What the container's CPU quota is worth in cores (cgroup v2 cpu.max, else v1), rounded up; 0: no quota / not known.
 inline int QuotaCpus() {
   double quota = 0, period = 0;
@@ -138,9 +192,54 @@ inline bool PinThreadToDeviceNode(int device, int max_cpus = 0, int window = -1)
     if (c < CPU_SETSIZE && CPU_ISSET(c, &now)) allowed.push_back(c);
   if (allowed.empty()) return false;
   const size_t n = allowed.size(), k = (max_cpus <= 0 || (size_t)max_cpus > n) ? n : (size_t)max_cpus;
-  // (window >= 0: the window-th stretch of k cores instead of the device's -- several groups of threads of one process)
-  const size_t first = ((size_t)(window >= 0 ? window : (device < 0 ? 0 : device)) * k) % n;
+  // (window >= 0: the window-th stretch of k cores instead of the device's)  The device's own stretch starts where its
+  // share of the node does -- the node's cores divided among the node's GPUs: four containers with a GPU each on one
+  // node would all take "device 0"'s first cores otherwise, and their spinning workers each other's time slices.
+  size_t first = ((size_t)(window >= 0 ? window : (device < 0 ? 0 : device)) * k) % n;
+  int rank = 0, count = 0;
+  if (window < 0 && DeviceRankOnNode(device, &rank, &count) && count > 0) {
+    size_t cores = n;  // (the list names one hardware thread of every core before the second: divide the first ones)
+    int smt = 0;
+    std::ifstream f("/sys/devices/system/cpu/smt/active");
+    if ((f >> smt) && smt == 1 && n >= 2) cores = n / 2;
+    first = (size_t)rank * (cores / (size_t)count) % n;
+  }
   for (size_t i = 0; i < k; ++i) CPU_SET(allowed[(first + i) % n], &want);
+  return sched_setaffinity(0, sizeof want, &want) == 0;
+}
+
+// Keeps the calling thread on the device's SHARE of its node: the node's cores divided among the node's GPUs (both
+// hardware threads of each) -- 16 cores = two L3 domains on an 8-GPU MI355X host.  For threads that spin (the lock-step
+// decoder's workers): fewer of them than cores in the share, so that whoever else wakes up there -- the runtime's own
+// threads, a neighbour's -- finds an idle sibling instead of taking a worker off its core; and close together, so that the
+// step's barrier stays inside two L3s.  The whole node where sysfs does not say how many GPUs share it.
+inline bool PinThreadToDeviceShare(int device) {
+  const std::vector<int> cpus = DeviceNodeCpus(device);
+  if (cpus.empty()) return false;
+  cpu_set_t now, want;
+  CPU_ZERO(&now);
+  CPU_ZERO(&want);
+  if (sched_getaffinity(0, sizeof now, &now) != 0) return false;
+  std::vector<int> allowed;
+  for (int c : cpus)
+    if (c < CPU_SETSIZE && CPU_ISSET(c, &now)) allowed.push_back(c);
+  if (allowed.empty()) return false;
+  const size_t n = allowed.size();
+  int rank = 0, count = 0, smt = 0;
+  {
+    std::ifstream f("/sys/devices/system/cpu/smt/active");
+    if (!(f >> smt)) smt = 0;
+  }
+  const size_t cores = (smt == 1 && n >= 2 && n % 2 == 0) ? n / 2 : n;
+  if (!DeviceRankOnNode(device, &rank, &count) || count <= 0 || cores / (size_t)count == 0) {
+    for (int c : allowed) CPU_SET(c, &want);
+  } else {
+    const size_t share = cores / (size_t)count, first = (size_t)rank * share;
+    for (size_t i = 0; i < share; ++i) {
+      CPU_SET(allowed[first + i], &want);
+      if (cores < n) CPU_SET(allowed[cores + first + i], &want);  // (the list names the second hardware threads behind the first)
+    }
+  }
   return sched_setaffinity(0, sizeof want, &want) == 0;
 }
 
@@ -613,19 +712,26 @@ class LockstepRunner {
     char* stack = nullptr;
     size_t stack_bytes = 0;
     bool done = false;
-    int slot = -1;             // its stream of the pool
+    int phase = 0;             // the set (pool) it belongs to
   };
-  // n_workers threads; fibre i runs on worker i % n_workers
-  LockstepRunner(MixerPool* pool, int n_workers) : pool_(pool), W_(n_workers < 1 ? 1 : n_workers), workers_(W_) {}
+  // n_workers threads; fibre i runs on worker i % n_workers.  n_phases: the fibres are in that many sets (pools), each
+  // with a lock step of its own, taken in turn by the SAME workers -- while one set's device step runs, the workers do
+  // the other set's host work (with one set they would spin through every step: at 256 files the host's turn and the
+  // device's are about as long as each other).
+  LockstepRunner(int n_workers, int n_phases = 1)
+      : W_(n_workers < 1 ? 1 : n_workers), P_(n_phases < 1 ? 1 : n_phases), live_(P_), inflight_(P_, 0) {
+    for (auto& l : live_) l.store(0);
+  }
   ~LockstepRunner() {
     for (auto& f : fibers_)
-      if (f->stack) munmap(f->stack, f->stack_bytes);
+      if (f && f->stack) munmap(f->stack, f->stack_bytes);
   }
-  // Before Run: a body for fibre `index` (bodies run in index order within a worker).
-  void Add(int index, std::function<void()> fn) {
+  // Before Run: a body for fibre `index` of set `phase` (bodies run in index order within a worker).
+  void Add(int index, int phase, std::function<void()> fn) {
     if ((int)fibers_.size() <= index) fibers_.resize(index + 1);
     std::unique_ptr<Fiber> f(new Fiber());
     f->fn = std::move(fn);
+    f->phase = phase;
     f->stack_bytes = kStackBytes;
     void* m = mmap(nullptr, kStackBytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
     if (m == MAP_FAILED) {
@@ -648,16 +754,25 @@ class LockstepRunner {
     gmx_fiber_switch(&f->sp, f->sched_sp);
   }
   // `setup(worker)` on every worker thread first (Predictor construction), then -- all of them done -- `join(worker)`
-  // (device banks, on the threads' own stacks), then the fibres until all have ended; `step()` by one thread, on its
-  // own stack, whenever every live fibre waits.  Returns the steps taken.
+  // (device banks, on the threads' own stacks), then the fibres, set by set, until all have ended: whenever every live
+  // fibre of a set waits, ONE thread, on its own stack, calls `launch(set)` (the set's device step, queued) and then
+  // `wait(next set)` (that one's answers are there), and the workers go on with the next set's fibres.  Returns the
+  // steps taken.
   uint64_t Run(const std::function<void(int)>& setup, const std::function<void(int)>& join,
-               const std::function<int()>& step) {
+               const std::function<int(int)>& launch, const std::function<int(int)>& wait) {
     std::vector<std::thread> threads;
-    live_.store((int)fibers_.size());
-    for (int w = 0; w < W_; ++w) threads.emplace_back([&, w] { Work(w, setup, join, step); });
+    lists_ = std::vector<List>((size_t)P_ * W_);
+    for (size_t i = 0; i < fibers_.size(); ++i) {
+      if (!fibers_[i]) continue;
+      live_[fibers_[i]->phase].fetch_add(1);
+      lists_[(size_t)fibers_[i]->phase * W_ + i % W_].f.push_back(fibers_[i].get());  // fibre i's home is worker i % W
+    }
+    for (int w = 0; w < W_; ++w) threads.emplace_back([&, w] { Work(w, setup, join, launch, wait); });
     for (auto& t : threads) t.join();
     return steps_;
   }
+  std::chrono::steady_clock::time_point setup_done() const { return t_setup_; }
+  std::chrono::steady_clock::time_point join_done() const { return t_join_; }
 
  private:
   static constexpr size_t kStackBytes = 1u << 20;
@@ -697,36 +812,64 @@ class LockstepRunner {
     }
   }
   void Work(int w, const std::function<void(int)>& setup, const std::function<void(int)>& join,
-            const std::function<int()>& step) {
+            const std::function<int(int)>& launch, const std::function<int(int)>& wait) {
     setup(w);
-    Barrier([] {});
+    Barrier([&] { t_setup_ = std::chrono::steady_clock::now(); });
     join(w);
-    Barrier([] {});
-    std::vector<Fiber*> mine;
-    for (size_t i = w; i < fibers_.size(); i += W_)
-      if (fibers_[i]) mine.push_back(fibers_[i].get());
+    Barrier([&] { t_join_ = std::chrono::steady_clock::now(); });
     for (;;) {
-      for (Fiber* f : mine) {
-        if (f->done) continue;
-        Resume(f);
-        if (f->done) live_.fetch_sub(1);
+      const int ph = cur_.load(std::memory_order_acquire);
+      // this worker's own fibres of the set first, then whatever the others have not got to yet: a worker whose core
+      // it shares with somebody else's thread (a busy host) would otherwise hold every step up with its whole list
+      for (int k = 0; k < W_; ++k) {
+        List& l = lists_[(size_t)ph * W_ + (w + k) % W_];
+        for (;;) {
+          const int i = l.next.fetch_add(1, std::memory_order_acq_rel);
+          if (i >= (int)l.f.size()) break;
+          Fiber* f = l.f[i];
+          if (f->done) continue;
+          Resume(f);
+          if (f->done) live_[ph].fetch_sub(1);
+        }
       }
       Barrier([&] {
-        // every live fibre of every worker waits for its step (or has just ended)
-        if (failed_.load() == 0 && step() != 0) failed_.store(1);
-        ++steps_;
-        finished_.store(live_.load() == 0 || failed_.load() != 0);
+        // every live fibre of this set, on every worker, waits for its step (or has just ended): queue the step; then
+        // the next set with anybody left -- this one again if it is the only one -- once ITS step's answers are there
+        for (int k = 0; k < W_; ++k) lists_[(size_t)ph * W_ + k].next.store(0, std::memory_order_relaxed);
+        bool failed = failed_.load() != 0;
+        if (!failed && live_[ph].load() > 0) {
+          if (launch(ph) != 0) failed = true;
+          inflight_[ph] = 1;
+          ++steps_;
+        }
+        int next = -1;
+        for (int k = 1; k <= P_ && next < 0; ++k)
+          if (live_[(ph + k) % P_].load() > 0) next = (ph + k) % P_;
+        if (!failed && next >= 0 && inflight_[next]) {
+          if (wait(next) != 0) failed = true;
+          inflight_[next] = 0;
+        }
+        if (failed) failed_.store(1);
+        finished_.store(failed || next < 0);
+        if (next >= 0) cur_.store(next, std::memory_order_release);
       });
       if (finished_.load()) break;
     }
   }
 
-  MixerPool* pool_;
-  const int W_;
-  struct Worker {};
-  std::vector<Worker> workers_;
+  struct List {  // the fibres of one set whose home is one worker, and how far into it the workers have got this turn
+    std::vector<Fiber*> f;
+    std::atomic<int> next{0};
+    List() {}
+    List(const List& o) : f(o.f), next(0) {}
+  };
+  const int W_, P_;
+  std::chrono::steady_clock::time_point t_setup_, t_join_;  // when every worker had finished `setup` / `join`
   std::vector<std::unique_ptr<Fiber>> fibers_;
-  std::atomic<int> arrived_{0}, live_{0}, failed_{0};
+  std::vector<List> lists_;
+  std::vector<std::atomic<int>> live_;   // per set: fibres that have not ended
+  std::vector<char> inflight_;           // per set: a step is queued (the barrier's one thread only)
+  std::atomic<int> arrived_{0}, failed_{0}, cur_{0};
   std::atomic<unsigned> gen_{0};
   std::atomic<bool> finished_{false};
   uint64_t steps_ = 0;
@@ -754,64 +897,78 @@ inline int LockstepDecompress(unsigned long long output_length, std::ifstream* i
   return rc ? rc : bank->status();
 }
 
-// What the groups of one BatchedDecompressFiles call share: constructions that draw from rand() (the host's own
-// LstmModel, lstm-layer.h:41) happen one at a time ACROSS groups, and no group brings up the device before every group's
-// Predictors stand (cf. RunManyFiles).
-struct DecompressSync {
-  std::mutex first_mu, serial_mu, mu;
-  std::mutex device_mu;  // one group at a time brings up its banks: a chainstep is CAPTURED into graphs on its group's
-                         // (blocking) stream, and any synchronous copy of another thread meanwhile -- the runtime's legacy
-                         // stream -- "would make the legacy stream depend on a capturing blocking stream" and fails both
-  std::condition_variable cv;
-  int groups = 1, constructed = 0;
-  bool serial = false;
-  void GroupConstructed() {
-    std::unique_lock<std::mutex> lk(mu);
-    ++constructed;
-    cv.notify_all();
-    if (serial) cv.wait(lk, [&] { return constructed >= groups; });
-  }
-};
-struct DecompressGroupResult {
-  std::chrono::steady_clock::time_point t_first, t0, t1;
-  uint64_t steps = 0;
-  int pinned = 0, workers = 0, pool_status = 0;
-  bool parallel_construction = false;
-  std::string error;
-};
-
-// One group: S files, one pool, W worker threads, window-th stretch of W cores of the device's node.
-inline void DecompressGroup(BatchedJob* jobs, int S, int W, int window, const BatchedOptions& opt, DecompressSync* sync,
-                            DecompressGroupResult* res) {
+// runner_utils::RunDecompression (runner-utils.cpp:123-156) for every job at once: a Predictor and a Decoder per file,
+// all device-side models of a pool of them one device step per coded bit.  opt.max_cpus worker threads (default: two
+// fewer than the container's CPU quota is worth, else the hardware's threads) carry the files' fibres.  opt.groups
+// pools (default one) are stepped in turn by the same workers: while one pool's device step runs, the workers do the
+// other pool's host work.  Returns the number of jobs that failed.
+inline int BatchedDecompressFiles(std::vector<BatchedJob>& jobs, const BatchedOptions& opt_in = BatchedOptions(),
+                                  BatchedStats* stats = nullptr) {
   using clock = std::chrono::steady_clock;
-  MixerPool pool(S, opt.device);
-  {
-    std::lock_guard<std::mutex> lk(sync->serial_mu);  // (the draw IS rand(): not beside a constructor that draws)
-    pool.DrawLstmInit();
+  const clock::time_point tb = clock::now();
+  BatchedOptions opt = opt_in;
+  const int S = (int)jobs.size();
+  if (S == 0) return 0;
+  // The workers spin at the step's barrier, so each is a core: two fewer than a container's CPU quota is worth leave
+  // the runtime's own threads their share (with workers = quota the run was throttled a dozen periods,
+  // profiles/r04_exp_decode_workers.txt; 8 .. 14 workers do the same within a few per cent)
+  int W = opt.max_cpus > 0 ? opt.max_cpus : (QuotaCpus() > 3 ? QuotaCpus() - 2 : QuotaCpus());
+  if (W <= 0) W = (int)std::thread::hardware_concurrency();
+  if (W <= 0) W = 1;
+  if (W > S) W = S;
+  int G = opt.groups > 0 ? opt.groups : 1;
+  if (G > S) G = S;
+  // file s belongs to pool s * G / S (whole stretches: the pools' streams are their files in order)
+  std::vector<int> pool_of(S);
+  std::vector<std::unique_ptr<MixerPool>> pools;
+  for (int g = 0; g < G; ++g) {
+    const int s0 = (int)((long long)S * g / G), s1 = (int)((long long)S * (g + 1) / G);
+    pools.emplace_back(new MixerPool(s1 - s0, opt.device));
+    pools.back()->DrawLstmInit();  // (the draw IS rand(): here, before any constructor runs)
+    for (int s = s0; s < s1; ++s) pool_of[s] = g;
   }
+  const clock::time_point t_pools = clock::now();
   std::vector<std::ifstream> in(S);
   std::vector<std::ofstream> out(S);
   std::vector<std::unique_ptr<Predictor>> preds(S);
-  std::mutex first_mu;
+  std::mutex first_mu, serial_mu;
+  std::mutex device_mu;  // several pools: their banks are brought up one thread at a time -- a chainstep is CAPTURED into
+                         // graphs on its group's (blocking) stream, and any synchronous copy of another pool's thread
+                         // meanwhile -- the runtime's legacy stream -- "would make the legacy stream depend on a
+                         // capturing blocking stream" and fails both
   std::condition_variable first_cv;
   bool first_built = false;
   std::atomic<int> pinned{0};
-  res->t_first = res->t0 = res->t1 = clock::now();
-  LockstepRunner runner(&pool, W);
-  pool.SetLockstepYield([](int) { LockstepRunner::Yield(); });
+  clock::time_point t_first = tb, t0 = tb;
+  LockstepRunner runner(W, G);
+  for (auto& p : pools) p->SetLockstepYield([](int) { LockstepRunner::Yield(); });
   std::vector<char> worker_pinned(W, 0);
   auto pin = [&](int w) {
     if (worker_pinned[w]) return;
     worker_pinned[w] = 1;
-    if (opt.pin_threads && PinThreadToDeviceNode(pool.device(), W, window)) ++pinned;
+    // (the device's share of the node, not W cores of it: W spinning workers on exactly W cores have nowhere to go when
+    // somebody else's thread wakes up on one of them -- on a shared host that was 10 000 preemptions a second and
+    // worker, and every one of them holds the step up: profiles/r04_exp_decode_busy_host.txt)
+    static const char* mode = getenv("GMX_PIN_MODE");  // (experiments: "narrow" = W cores, "node" = the whole node)
+    bool ok = false;
+    if (!opt.pin_threads) return;
+    if (mode && !strcmp(mode, "narrow"))
+      ok = PinThreadToDeviceNode(pools[0]->device(), W);
+    else if (mode && !strcmp(mode, "node"))
+      ok = PinThreadToDeviceNode(pools[0]->device(), 0);
+    else
+      ok = PinThreadToDeviceShare(pools[0]->device());
+    if (ok) ++pinned;
   };
+  // (known once the first Predictor stands: whether a constructor draws from rand(), MixerPool::parallel_construction)
+  std::atomic<bool> side_by_side{false};
   // A fibre runs the reference's Decoder and nothing that calls the device: the banks are brought up and joined
   // (BeginLockstep) on the worker threads' own stacks before the fibres start, every step is taken there too, and a
   // fibre's last act is the wait for its last Learn.  (Runtime and profiler code on a 1 MB foreign stack: rocprofv3
   // around this very loop died with a segmentation fault while BeginLockstep still ran inside the fibres.)
   std::vector<std::shared_ptr<GpuMixerBank>> banks(S);
   for (int s = 0; s < S; ++s) {
-    runner.Add(s, [&, s] {
+    runner.Add(s, pool_of[s], [&, s] {
       BatchedJob& job = jobs[s];
       if (job.status || !banks[s]) return;
       const clock::time_point a = clock::now();
@@ -829,11 +986,10 @@ inline void DecompressGroup(BatchedJob* jobs, int S, int W, int window, const Ba
       out[s].close();
     });
   }
-  std::atomic<int> setups_left{W};
   auto setup = [&](int w) {
-    pool.InstallForThisThread();  // this thread's Predictors are this group's pool's
     for (int s = w; s < S; s += W) {
       BatchedJob& job = jobs[s];
+      pools[pool_of[s]]->InstallForThisThread();  // the Predictor about to be built is that pool's
       in[s].open(job.input_path, std::ios::in | std::ios::binary);
       bool ok = in[s].is_open();
       if (ok) {
@@ -845,21 +1001,14 @@ inline void DecompressGroup(BatchedJob* jobs, int S, int W, int window, const Ba
         ok = out[s].is_open();
       }
       if (!ok) job.status = -100;
-      // (construction as in RunManyFiles: the first Predictor alone -- alone among ALL groups --, the others side by side
-      // when no constructor draws, else one at a time across the groups)
+      // (construction as in RunManyFiles: the first Predictor alone, the others side by side when no constructor draws
+      // from rand(), else one at a time)
       if (s == 0) {
-        {
-          std::lock_guard<std::mutex> one(sync->first_mu);
-          std::lock_guard<std::mutex> two(sync->serial_mu);  // (another group's later Predictors may be drawing)
-          if (ok) preds[0].reset(new Predictor());
-          if (!pool.parallel_construction()) {
-            std::lock_guard<std::mutex> lk(sync->mu);
-            sync->serial = true;
-          }
-        }
+        if (ok) preds[0].reset(new Predictor());
+        side_by_side.store(pools[0]->parallel_construction());
         std::lock_guard<std::mutex> lk(first_mu);
         first_built = true;
-        res->t_first = clock::now();
+        t_first = clock::now();
         first_cv.notify_all();
         continue;
       }
@@ -868,20 +1017,23 @@ inline void DecompressGroup(BatchedJob* jobs, int S, int W, int window, const Ba
         first_cv.wait(lk, [&] { return first_built; });
       }
       if (!ok) continue;
-      if (pool.parallel_construction()) {
+      if (side_by_side.load()) {
         pin(w);
         preds[s].reset(new Predictor());
       } else {
-        std::lock_guard<std::mutex> lk(sync->serial_mu);
+        std::lock_guard<std::mutex> lk(serial_mu);
         preds[s].reset(new Predictor());
       }
     }
-    if (setups_left.fetch_sub(1) == 1) sync->GroupConstructed();  // (the group's last worker; waits for the others if serial)
+    MixerPool::UninstallForThisThread();
   };
-  // ... and, every Predictor standing: the device banks (the first to get here creates them for all), each stream's join
+  // ... and, every Predictor standing: the device banks (the first to get here creates a pool's for all), each stream's join
   auto join = [&](int w) {
     pin(w);  // (where constructors draw from rand() the threads are only pinned now)
-    std::lock_guard<std::mutex> one_group(sync->device_mu);
+    // (one pool: its own mutex orders what has to be; the streams' uploads run side by side -- one after the other they
+    // were 15 s for 256 files)
+    std::unique_lock<std::mutex> one_at_a_time(device_mu, std::defer_lock);
+    if (G > 1) one_at_a_time.lock();
     for (int s = w; s < S; s += W) {
       if (!preds[s] || jobs[s].status) continue;
       banks[s] = GpuMixerBank::Of(preds[s].get(), sizeof(Predictor));
@@ -895,82 +1047,53 @@ inline void DecompressGroup(BatchedJob* jobs, int S, int W, int window, const Ba
     }
   };
   bool started = false;
-  res->steps = runner.Run(setup, join, [&] {
-    if (!started) {
-      started = true;
-      res->t0 = clock::now();  // (the first step: every fibre has built nothing more than its first record)
-    }
-    return pool.StepAll();
-  });
-  res->t1 = clock::now();
-  pool.SetLockstepYield(nullptr);
+  const uint64_t steps = runner.Run(
+      setup, join,
+      [&](int g) {
+        if (!started) {
+          started = true;
+          t0 = clock::now();  // (the first step: every fibre of the first pool has built nothing more than its first record)
+        }
+        return pools[g]->StepLaunch();
+      },
+      [&](int g) { return pools[g]->StepWait(); });
+  const clock::time_point t1 = clock::now();
+  if (getenv("GMX_POOL_TRACE")) {
+    auto sec = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    fprintf(stderr, "[gmx decode] %d files, %d workers, %d pool(s): pools %.2f s, Predictors (first alone: %.2f s) %.2f s, "
+            "device banks and joins %.2f s, first records %.2f s, %llu steps %.2f s\n", S, W, G, sec(tb, t_pools),
+            sec(tb, t_first), sec(t_pools, runner.setup_done()), sec(runner.setup_done(), runner.join_done()),
+            sec(runner.join_done(), t0), (unsigned long long)steps, sec(t0, t1));
+  }
+  for (auto& p : pools) p->SetLockstepYield(nullptr);
   if (opt.destroy_predictors) {
-    preds.clear();
+    // side by side, like their construction: a Predictor gives back gigabytes of touched pages, and one thread's munmap
+    // after another's is all a process's exit would do about them either
+    std::vector<std::thread> th;
+    for (int w = 0; w < W; ++w)
+      th.emplace_back([&, w] {
+        for (int s = w; s < S; s += W) preds[s].reset();
+      });
+    for (auto& t : th) t.join();
   } else {
     for (auto& p : preds) p.release();
+    for (auto& p : pools) p.release();  // (their banks live in the pools)
   }
-  res->pinned = pinned.load();
-  res->workers = W;
-  res->parallel_construction = pool.parallel_construction();
-  res->pool_status = pool.status();
-  if (res->pool_status) res->error = pool.error();
-}
-
-// runner_utils::RunDecompression (runner-utils.cpp:123-156) for every job at once: a Predictor and a Decoder per file,
-// all device-side models of a group of them one device step per coded bit.  opt.max_cpus worker threads in all
-// (default: two fewer than the container's CPU quota is worth, else the hardware's threads) carry the files' fibres;
-// opt.groups groups (default one) each have a pool, their share of the workers and a lock step of their own.  Returns the
-// number of jobs that failed.
-inline int BatchedDecompressFiles(std::vector<BatchedJob>& jobs, const BatchedOptions& opt_in = BatchedOptions(),
-                                  BatchedStats* stats = nullptr) {
-  using clock = std::chrono::steady_clock;
-  const clock::time_point tb = clock::now();
-  BatchedOptions opt = opt_in;
-  const int S = (int)jobs.size();
-  if (S == 0) return 0;
-  // The workers spin at the step's barrier, so each is a core: two fewer than a container's CPU quota is worth leave
-  // the runtime's own threads their share (with workers = quota the group was throttled a dozen periods per run,
-  // profiles/r04_exp_decode_workers.txt; 8 .. 14 workers do the same within a few per cent)
-  int W = opt.max_cpus > 0 ? opt.max_cpus : (QuotaCpus() > 3 ? QuotaCpus() - 2 : QuotaCpus());
-  if (W <= 0) W = (int)std::thread::hardware_concurrency();
-  if (W <= 0) W = 1;
-  if (W > S) W = S;
-  int G = opt.groups > 0 ? opt.groups : 1;
-  if (G > W) G = W;
-  if (G > S) G = S;
-  DecompressSync sync;
-  sync.groups = G;
-  std::vector<DecompressGroupResult> res(G);
-  std::vector<std::thread> threads;
-  for (int g = 0; g < G; ++g) {
-    const int s0 = (int)((long long)S * g / G), s1 = (int)((long long)S * (g + 1) / G);
-    const int w0 = (int)((long long)W * g / G), w1 = (int)((long long)W * (g + 1) / G);
-    threads.emplace_back([&, g, s0, s1, w0, w1] {
-      DecompressGroup(jobs.data() + s0, s1 - s0, std::max(1, std::min(w1 - w0, s1 - s0)), G > 1 ? g : -1, opt, &sync, &res[g]);
-    });
-  }
-  for (auto& t : threads) t.join();
   int failed = 0;
   for (auto& j : jobs) failed += j.status != 0;
-  for (auto& r : res)
-    if (r.pool_status != 0) fprintf(stderr, "gmx::BatchedDecompressFiles: %s\n", r.error.c_str());
+  for (auto& p : pools)
+    if (p && p->status() != 0) fprintf(stderr, "gmx::BatchedDecompressFiles: %s\n", p->error().c_str());
   if (stats) {
     const clock::time_point tz = clock::now();
-    clock::time_point t0 = res[0].t0, t1 = res[0].t1, tf = res[0].t_first;
-    for (auto& r : res) {
-      t0 = std::min(t0, r.t0);
-      t1 = std::max(t1, r.t1);
-      tf = std::min(tf, r.t_first);
-      stats->launches += r.steps;
-      stats->pinned_threads += r.pinned;
-      stats->pinned_cpus += r.workers;
-    }
+    stats->launches += steps;
+    stats->pinned_threads += pinned.load();
+    stats->pinned_cpus += W;
     stats->total_seconds = std::chrono::duration<double>(tz - tb).count();
     stats->wall_seconds = std::chrono::duration<double>(t1 - t0).count();
     stats->build_seconds = std::chrono::duration<double>(t0 - tb).count();
-    stats->first_predictor_seconds = std::chrono::duration<double>(tf - tb).count();
+    stats->first_predictor_seconds = std::chrono::duration<double>(t_first - tb).count();
     stats->teardown_seconds = std::chrono::duration<double>(tz - t1).count();
-    stats->parallel_construction = res[0].parallel_construction;
+    stats->parallel_construction = side_by_side.load();
     for (auto& j : jobs) stats->bits += 8ull * j.output_bytes;
   }
   return failed;

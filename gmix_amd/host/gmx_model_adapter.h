@@ -265,6 +265,26 @@ class MixerPool {
     }
     return rc;
   }
+  // The same in two halves (a scheduler with two pools: one's host work beside the other's device step).
+  int StepLaunch() {
+    if (!cs_ || status_.load()) return status_.load();
+    std::lock_guard<std::mutex> lk(mu_);
+    const int rc = gmx_chainstep_launch(cs_);
+    if (rc) {
+      Fail("gmx_chainstep_launch", rc);
+      return rc;
+    }
+    memset(ls_what_, 0, (size_t)S_);
+    ++round_;
+    return GMX_OK;
+  }
+  int StepWait() {
+    if (!cs_ || status_.load()) return status_.load();
+    std::lock_guard<std::mutex> lk(mu_);
+    const int rc = gmx_chainstep_wait(cs_);
+    if (rc) Fail("gmx_chainstep_wait", rc);
+    return rc;
+  }
   int lockstep_streams() const { return ls_participants_; }
 
  private:

@@ -432,7 +432,11 @@ int gmx_lstm_memory_usage(gmx_lstm* l, uint64_t* bytes);
  * where the host can store into device memory the library moves them there right away, in the calling thread (S decoders
  * on several threads: each commits its own streams, any number of threads at once, before the one that calls
  * gmx_chainstep_step); streams nobody committed are moved by gmx_chainstep_step itself.  Nothing of stream s may be
- * written between its commit and the step. */
+ * written between its commit and the step.
+ * gmx_chainstep_launch / gmx_chainstep_wait: gmx_chainstep_step in two halves -- launch returns with the step queued
+ * (and `what` free to be cleared), wait with p / outputs in place -- for a caller that drives two objects alternately,
+ * one's host work beside the other's device step.  Between the two, nothing of the object may be written or committed
+ * (GMX_ERR_STATE). */
 #define GMX_STEP_LEARN 1u
 #define GMX_STEP_PREDICT 2u
 typedef struct gmx_chainstep gmx_chainstep;
@@ -452,6 +456,8 @@ const float* gmx_chainstep_p(gmx_chainstep* cs);         /* [S] */
 const float* gmx_chainstep_outputs(gmx_chainstep* cs);   /* [S][M] */
 int gmx_chainstep_commit(gmx_chainstep* cs, int stream);
 int gmx_chainstep_step(gmx_chainstep* cs);
+int gmx_chainstep_launch(gmx_chainstep* cs);
+int gmx_chainstep_wait(gmx_chainstep* cs);
 
 /* ==== Compute-unit shares ======================================================================
  * A bank's kernels normally spread over the whole chip.  Kernels of DIFFERENT banks that cannot share

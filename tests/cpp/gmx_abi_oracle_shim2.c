@@ -469,6 +469,9 @@ uint8_t* gmx_chainstep_what(gmx_chainstep* cs) { return cs->what; }
 const float* gmx_chainstep_p(gmx_chainstep* cs) { return cs->p; }
 const float* gmx_chainstep_outputs(gmx_chainstep* cs) { return cs->outs; }
 int gmx_chainstep_commit(gmx_chainstep* cs, int s) { return (cs && s >= 0 && s < cs->S) ? GMX_OK : GMX_ERR_INVALID; }
+int gmx_chainstep_step(gmx_chainstep* cs);
+int gmx_chainstep_launch(gmx_chainstep* cs) { return gmx_chainstep_step(cs); }  /* (the CPU stand-in has nothing to overlap) */
+int gmx_chainstep_wait(gmx_chainstep* cs) { return cs ? GMX_OK : GMX_ERR_INVALID; }
 int gmx_chainstep_step(gmx_chainstep* cs) {
   if (!cs) return GMX_ERR_INVALID;
   for (int s = 0; s < cs->S; ++s) {

@@ -50,10 +50,16 @@ def chain_stream(oracle, models, tabs, topo, slots, NB, seed, rng, lstm_slot=1, 
                 mo=mo, io=io, lm=lm)
 
 
-def test_chain_in_lock_step_equals_oracle_chain(gpu, oracle):
+@pytest.mark.parametrize("path", ["step", "commit", "device_fetch"])
+def test_chain_in_lock_step_equals_oracle_chain(gpu, oracle, path, monkeypatch):
     """Three streams of 130 / 101 / 7 bytes (an LSTM backward pass at byte 100 inside the first two; the third ends
     early and sits the remaining steps out; each stream's last step is a learn alone).  Every probability and all 33
-    outputs of every bit, and the three banks' state at the end, equal the oracle chain's."""
+    outputs of every bit, and the three banks' state at the end, equal the oracle chain's.  The three ways a step's
+    inputs reach the device: gmx_chainstep_step moving them into device memory itself; the caller committing stream by
+    stream (what the decoders' threads do) and taking the step in its two halves, launch and wait; and -- as on a host
+    without a large BAR -- the step's first kernel fetching them from pinned memory."""
+    if path == "device_fetch":
+        monkeypatch.setenv("GMX_CS_NO_BAR", "1")
     _, z = goldenlib.load("ind_stock41")
     tabs = (z["ns_next"], z["rm_next"])
     models = topology.stock_indirect()
@@ -82,7 +88,16 @@ def test_chain_in_lock_step_equals_oracle_chain(gpu, oracle):
                 if t % 8 == 0:
                     cs.ppm[s] = x["ppm"][t // 8]
             cs.what[s] = w
-        cs.step()
+            if path == "commit" and w:
+                cs.commit(s)
+        if path == "commit":
+            cs.launch()
+            if t == 3:
+                with pytest.raises(gpu.GmxError):   # nothing of the object is committed while its step is under way
+                    cs.commit(0)
+            cs.wait()
+        else:
+            cs.step()
         for s, x in enumerate(st):
             if t < x["T"]:
                 assert cs.p[s].view(np.uint32) == x["p"][t].view(np.uint32), (s, t)
