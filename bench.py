@@ -400,10 +400,20 @@ def main():
         sys.stderr.write(f"[bench] rank {rank}: not pinned to its GPU's NUMA node ({e})\n")
     comm = Comm(dist, world, rank, pinned)
 
+    t_sections, t_mark = {}, time.perf_counter()
+
+    def section(name):   # wall seconds of the bench's own sections (rank 0's clock): where a default run's minutes go
+        nonlocal t_mark
+        now = time.perf_counter()
+        t_sections[name] = round(t_sections.get(name, 0.0) + now - t_mark, 1)
+        t_mark = now
+
+    section("setup")
     head = run_workload(args.config, comm, local_rank, streams=args.streams, bits=args.bits, steps=args.steps,
                         warmup=args.warmup, ring_n=args.ring, ctx_mode=args.ctx_mode, ctx_mod=args.ctx_mod,
                         stock_pairs=args.stock_pairs, variant=args.variant, want_cpu=not args.no_cpu_baseline,
                         cpu_sample_bits=args.cpu_sample_bits)
+    section(args.config)
     also = {}
     only = {x for x in args.only_also.split(",") if x}
     if not args.no_also:
@@ -422,6 +432,7 @@ def main():
                 r = {"error": f"{type(e).__name__}: {e}"}
             if rank == 0:
                 also[name] = r
+            section(name)
         if rank == 0 and "cpu_baseline" in also.get("stock_held", {}) and "error" not in also.get("stock_S1", {"error": 1}):
             # one stream of the same workload: the one-core reference figure is the same measurement
             also["stock_S1"]["cpu_baseline"] = dict(also["stock_held"]["cpu_baseline"])
@@ -457,6 +468,7 @@ def main():
                                               c.get("bytes_per_stream_per_step")), 0, rf.get("build")))
                 except Exception as e:
                     also[name] = {"error": f"{type(e).__name__}: {e}"}
+                section(name)
         elif "e2e_S64" in only:
             # (only when asked for: --only-also e2e_S64.)  Whole files on every GPU at once (weak scaling: a process per
             # GPU, no exchange): every rank compresses its own files on its own device -- as many as the host's CPU
@@ -505,7 +517,7 @@ def main():
             out["also"] = also
         # ... and once more as the line's LAST object: a reader who keeps only the end of a long line (the driver's
         # record holds the last 2 000 characters) still sees every fraction and the whole-file figures
-        out["tail_summary"] = {"fracs": fracs, "e2e": e2e}
+        out["tail_summary"] = {"fracs": fracs, "e2e": e2e, "bench_seconds": t_sections}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

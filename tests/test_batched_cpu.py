@@ -57,8 +57,8 @@ def test_reference_tester_with_batched_compression(tmp_path):
     left behind -- the tester itself compares their files with the batched one, and everything it leaves equals
     the stock build's."""
     _skip_unless("ref_tester_strict", "ref_tester_batched_shim", "ref_tester_chain_batched_shim")
-    stock, batched, chain = run_all([("ref_tester_strict", 300), ("ref_tester_batched_shim", 300),
-                                     ("ref_tester_chain_batched_shim", 300)], 1200, tmp_path)
+    stock, batched, chain = run_all([("ref_tester_strict", 200), ("ref_tester_batched_shim", 200),
+                                     ("ref_tester_chain_batched_shim", 200)], 800, tmp_path)
     compare(stock, batched)
     compare(stock, chain)
 
@@ -66,27 +66,27 @@ def test_reference_tester_with_batched_compression(tmp_path):
 @pytest.mark.parametrize("exe,chunk", [("gmix_batched_ckpt_shim", 2048), ("gmix_chain_batched_ckpt_shim", 1000)])
 def test_state_left_behind_equals_the_per_bit_loop(tmp_path, exe, chunk):
     """What a run-ahead compression LEAVES: Predictor::WriteCheckpoint straight after gmx::BatchedCompressor over
-    601 bytes equals the checkpoint the reference's tester writes after the same 601 bytes through its
+    401 bytes equals the checkpoint the reference's tester writes after the same 401 bytes through its
     Predict/Encode/Perceive/Learn loop (tester.cpp:32-59) -- the banks' state as the reference's serialisers write
     it, the blackboard (mixer outputs, final output, lstm_prediction_context from the device in `chain`), the
     LSTM's byte-range state, every host model."""
     _skip_unless("ref_tester_strict", exe)
-    (stock,) = run_all([("ref_tester_strict", 0)], 1200, tmp_path)
-    ck = checkpoint_after_batches(exe, stock, 1200, chunk, tmp_path)
+    (stock,) = run_all([("ref_tester_strict", 0)], 800, tmp_path)
+    ck = checkpoint_after_batches(exe, stock, 800, chunk, tmp_path)
     same_checkpoint(os.path.join(stock, "restart"), ck)
 
 
 @pytest.mark.parametrize("exe,side_by_side", [("gmix_chain_many_shim", True), ("gmix_many_shim", False)])
 def test_predictors_built_side_by_side_where_no_constructor_draws(tmp_path, exe, side_by_side):
-    """Eight files.  With the LSTM on the device its initial weights -- a constant: every Predictor constructor begins
+    """Four files.  With the LSTM on the device its initial weights -- a constant: every Predictor constructor begins
     with srand(0xDEADBEEF), predictor.cpp:18 -- come from the pool's one draw (MixerPool::DrawLstmInit) and the
     Predictors behind the first are constructed at once on their threads; with the host's own LstmModel drawing from
     rand() (lstm-layer.h:41) constructions stay serial.  Either way every file is the stock build's."""
     _skip_unless("gmix_strict", exe)
     files = []
-    for k in range(8):
+    for k in range(4):
         f = tmp_path / f"f{k}"
-        f.write_bytes(corpus(150 + 31 * k, 2500 * k))
+        f.write_bytes(corpus(110 + 31 * k, 2500 * k))
         files.append(f)
     st = run_many(exe, files, tmp_path / "out", 256)
     assert st["failed"] == 0 and st["parallel_construction"] is side_by_side
