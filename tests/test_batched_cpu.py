@@ -103,8 +103,9 @@ def test_many_files_restored_in_lock_step(tmp_path, exe, cpus, groups):
     """gmx::BatchedDecompressFiles: five files the STOCK build compressed (0 / 1 / 613 / 300 / 613 bytes) restored
     together -- the reference's own Decoder per file, each on a fibre, `cpus` worker threads, one gmx_chainstep step per
     coded bit for all of them; files that end early sit the remaining steps out, every file's last Learn is a step
-    without a Predict.  `groups` > 1: the files in that many groups, each a pool, workers and a lock step of its own
-    (Predictors that draw from rand() -- the mixers-only build -- still constructed one at a time across the groups).
+    without a Predict.  `groups` > 1: the files in that many pools, each a lock step of its own, taken in turn by the same
+    workers, who also take over each other's fibres (Predictors that draw from rand() -- the mixers-only build -- still
+    constructed one at a time).
     Byte-identical to the inputs."""
     _skip_unless("gmix_strict", exe)
     files, coded = [], []

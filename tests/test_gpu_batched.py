@@ -115,8 +115,9 @@ def test_files_restored_side_by_side_in_lock_step(gpu, tmp_path, exe, n_files, b
     a fibre of a few worker threads; every coded bit of all files is ONE gmx_chainstep step -- LSTM, 41 Indirect models and
     33 mixers of all streams in one hipGraph (gmix_many: the mixers alone).  Files the run-ahead compressor wrote AND
     files the stock build wrote (`gmix_strict -c`) are restored byte for byte; lengths differ, so streams leave one by
-    one.  groups = 2: the files in two groups, each a pool and a lock step of its own (their banks brought up one group
-    at a time: a synchronous copy beside another thread's graph capture fails both)."""
+    one.  groups = 2: the files in two pools, each a lock step of its own, taken in turn by the same worker threads --
+    gmx_chainstep_launch of one, the other's fibres, gmx_chainstep_wait (their banks brought up one thread at a time: a
+    synchronous copy beside another thread's graph capture fails both)."""
     need("gmix_strict", exe)
     files = []
     for k in range(n_files):
