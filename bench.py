@@ -425,7 +425,7 @@ def main():
                 div = max(1, args.also_streams_div)
                 r = run_workload(name, comm, local_rank, warmup=2, ring_n=2,
                                  streams=max(1, WORKLOADS[name][2] // div) if div > 1 else None,
-                                 want_cpu=not args.no_cpu_baseline and name != "stock_S1")
+                                 want_cpu=not args.no_cpu_baseline and name not in ("stock_S1", "single_S1"))
             except Exception as e:  # a sub-result must never cost the headline line
                 if dist is not None:
                     raise  # ... except across ranks, where a lone failure would leave the others in a barrier
@@ -436,6 +436,8 @@ def main():
         if rank == 0 and "cpu_baseline" in also.get("stock_held", {}) and "error" not in also.get("stock_S1", {"error": 1}):
             # one stream of the same workload: the one-core reference figure is the same measurement
             also["stock_S1"]["cpu_baseline"] = dict(also["stock_held"]["cpu_baseline"])
+        if rank == 0 and "cpu_baseline" in head and args.config == "single" and "error" not in also.get("single_S1", {"error": 1}):
+            also["single_S1"]["cpu_baseline"] = dict(head["cpu_baseline"])   # (likewise: the headline's own, 15 s of one core)
         if dist is None:
             # the producers in front of the mixers, timed by their own scripts' code:
             # the 41 Indirect models (bits/s) and the LSTM byte model (bytes/s), each with roofline + cpu_baseline
