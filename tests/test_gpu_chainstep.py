@@ -47,7 +47,7 @@ def chain_stream(oracle, models, tabs, topo, slots, NB, seed, rng, lstm_slot=1, 
     act_host[:, :8] = act_o[:, :8]
     act_host[:, lstm_slot] = 0
     return dict(T=T, ppm=ppm, bits=bits, bc=bc, ictx=ictx, mctx=mctx, other=other, act=act_host, p=p_ref, o=o_ref,
-                mo=mo, io=io, lm=lm)
+                mo=mo, io=io, lm=lm, pred_all=pred, act_all=act, ictx_ref=ictx_ref, mctx_ref=mctx_ref)
 
 
 @pytest.mark.parametrize("path", ["step", "commit", "device_fetch"])
@@ -112,10 +112,77 @@ def test_chain_in_lock_step_equals_oracle_chain(gpu, oracle, path, monkeypatch):
         x.close()
 
 
-@pytest.mark.parametrize("kind", ["stock", "synth3"])
-def test_mixers_alone_in_lock_step(gpu, oracle, kind):
+@pytest.mark.parametrize("family,device_fetch", [("indirect", False), ("lstm", False), ("indirect", True), ("lstm", True)])
+def test_one_model_family_on_the_device(gpu, oracle, family, device_fetch, monkeypatch):
+    """gmx_chainstep with the Indirect models but no LSTM, and with the LSTM but no Indirect models: what the absent family
+    would have produced -- predictions, active bits, lstm_prediction_context in the context columns that read it --
+    comes in the caller's records like any host-side model's (the oracle chain's own values), and the step's launches
+    are the family's kernel on its own (gmx_indirect_step_kernel<false> / gmx_lstm_bitstep_kernel) in front of the
+    mixers'.  Two streams of 27 and 10 bytes; every probability and output, and the banks at the end.  device_fetch: the
+    step's inputs fetched by a launch of their own at its head (gmx_step_upload_kernel), as on a host without a large BAR."""
+    if device_fetch:
+        monkeypatch.setenv("GMX_CS_NO_BAR", "1")
+    _, z = goldenlib.load("ind_stock41")
+    tabs = (z["ns_next"], z["rm_next"])
+    models = topology.stock_indirect()
+    topo = topology.stock(90)
+    K, S = len(models), 2
+    slots = [(8 + 2 * i, 9 + 2 * i) for i in range(K)]
+    rng = np.random.default_rng(6)
+    st = [chain_stream(oracle, models, tabs, topo, slots, nb, 50 + s, rng) for s, nb in enumerate((27, 10))]
+    mg = gpu.MixerGroup(topo, S)
+    ig = gpu.IndirectGroup(models, *tabs, S, slots=slots) if family == "indirect" else None
+    lg = gpu.LstmGroup(S) if family == "lstm" else None
+    if lg:
+        for s in range(S):
+            lg.set_weights(oracle.LstmModel().weights(), stream=s)
+    cs = gpu.ChainStep(mg, ig, lg, lstm_slot=1 if lg else -1, mixer_ctx_col=22 if lg else -1)
+    dev_slots = [i for ab in slots for i in ab] if ig else [1]   # what the device fills in itself
+    for t in range(max(x["T"] for x in st) + 1):
+        for s, x in enumerate(st):
+            w = 0
+            if 0 < t <= x["T"]:
+                w |= LEARN
+                cs.bits[s] = x["bits"][t - 1]
+            if t < x["T"]:
+                w |= PREDICT
+                cs.predictions[s, :90] = x["pred_all"][t]
+                act = x["act_all"][t].copy()
+                act[dev_slots] = 0
+                cs.set_active(s, act)
+                cs.contexts[s] = x["mctx_ref"][t] if ig else x["mctx"][t]
+                if ig:
+                    cs.ind_contexts[s] = x["ictx_ref"][t]
+                    cs.bit_contexts[s] = x["bc"][t]
+                if lg and t % 8 == 0:
+                    cs.ppm[s] = x["ppm"][t // 8]
+            cs.what[s] = w
+        cs.step()
+        for s, x in enumerate(st):
+            if t < x["T"]:
+                assert cs.p[s].view(np.uint32) == x["p"][t].view(np.uint32), (s, t)
+                assert np.array_equal(u32(cs.outputs[s]), u32(x["o"][t])), (s, t)
+    cs.close()
+    for s, x in enumerate(st):
+        assert mg.export(s) == (x["mo"].export_long(), x["mo"].export_short()), s
+        if ig:
+            assert ig.export(s) == x["io"].export(), s
+        if lg:
+            w, o = lg.get_weights(s)
+            assert np.array_equal(u32(w), u32(x["lm"].weights())) and np.array_equal(u32(o), u32(x["lm"].output_layer())), s
+    for x in (lg, ig, mg):
+        if x:
+            x.close()
+
+
+@pytest.mark.parametrize("kind", ["stock", "synth3", "stock_device_fetch"])
+def test_mixers_alone_in_lock_step(gpu, oracle, kind, monkeypatch):
     """gmx_chainstep without Indirect models and LSTM: the caller's records carry all inputs (the mixers-only drop-in).
-    The reference's shape through gmx_stock_kernel, the 256-input 24/8/1 bank through the general kernel."""
+    The reference's shape through gmx_stock_step_kernel (its inputs stored by the host, or fetched by the upload launch),
+    the 256-input 24/8/1 bank through a learn and a forward launch of the general kernel."""
+    if kind == "stock_device_fetch":
+        monkeypatch.setenv("GMX_CS_NO_BAR", "1")
+        kind = "stock"
     topo = topology.stock(90) if kind == "stock" else topology.synth3(256, table0=1 << 8)
     N, M, S, T = topo.n_inputs, topo.n_mixers, 4, 300
     mg = gpu.MixerGroup(topo, S)
