@@ -235,5 +235,20 @@ def test_step_protocol_errors(gpu):
     cs.step()                            # nobody asks: nothing happens
     cs.what[:] = [LEARN, 0]
     cs.step()
+    # the step in two halves: a second launch before the wait is refused, and so is a commit; waiting twice is not
+    cs.what[:] = [PREDICT, PREDICT]
+    cs.launch()
+    with pytest.raises(gpu.GmxError):
+        cs.launch()
+    with pytest.raises(gpu.GmxError):
+        cs.commit(1)
+    cs.wait()
+    cs.wait()
+    with pytest.raises(gpu.GmxError):   # no such stream
+        cs.commit(2)
+    cs.what[:] = [LEARN, LEARN]
+    cs.bits[:] = [0, 1]
+    cs.commit(0)
+    cs.step()
     cs.close()
     mg.close()
