@@ -3,13 +3,19 @@
 // Linked by dropin/Makefile against the reference's own translation units (feature models, coder,
 // runner-utils) with Predictor::AddMixers constructing gmx::GpuMixer -- the reference calls the product.
 //
-// usage: gmix_many [-d] [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--groups g] [--destroy] [--device d] <out dir> <input file>...
+// usage: gmix_many [-d] [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--groups g] [--destroy] [--plain-exit] [--device d] <out dir> <input file>...
 //   each input is compressed to <out dir>/<index>.gmix exactly as `gmix -c` would (runner-utils.cpp:88-121);
 //   -n limits every input to its first n bytes (written to <out dir>/<index>.in first).
 //   -d: each input is a file `gmix -c` wrote and is restored to <out dir>/<index>.out as `gmix -d` would
 //   (runner-utils.cpp:123-156), all files together through gmx::BatchedDecompressFiles (Decoders in lock step).
 //   One JSON line on stdout: per-file sizes and times, the wall time of the compression phase, bits, launches.
+#include <malloc.h>
+#include <sys/mman.h>
 #include <sys/resource.h>
+#include <atomic>
+#include <mutex>
+#include <new>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,6 +26,69 @@
 #include <vector>
 
 #include "gmx_batched.h"
+
+// ---- the process's end.  Every Predictor has TOUCHED about 2 GB (PPMd's arena is one `new byte[2000 << 20]`,
+// mod_ppmd.cpp:127-128), and a process that just ends gives its pages back on ONE core: 1.3 s for 64 files, 5-6 s for
+// 256 -- where the reference's CLI, a process per file, gives back 2 GB at a time on as many cores as it has processes.
+// This driver therefore remembers its big allocations (a replaced global operator new, [replacement.functions]: the
+// reference allocates with new / new[] / std::vector) and, when everything is written and closed, hands their pages
+// back from all its threads at once -- madvise(MADV_DONTNEED) takes the address space's lock shared, so the threads'
+// page freeing runs side by side -- before it ends.  Nothing is skipped: the same pages are freed, by more cores.
+namespace {
+constexpr size_t kBigAllocation = 32u << 20;
+std::mutex g_big_mu;
+std::vector<std::pair<char*, size_t>>* g_big = nullptr;  // (a pointer: alive until _exit, never destroyed)
+bool g_release_pages = true;
+
+void ReleaseBigAllocations(int n_threads) {
+  std::vector<std::pair<char*, size_t>> slices;
+  {
+    std::lock_guard<std::mutex> lk(g_big_mu);
+    if (!g_big) return;
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE), slice = 64u << 20;
+    for (auto& b : *g_big) {
+      char* lo = (char*)(((uintptr_t)b.first + page - 1) / page * page);
+      char* const hi = (char*)(((uintptr_t)b.first + b.second) / page * page);
+      for (; lo < hi; lo += slice) slices.emplace_back(lo, (size_t)std::min<ptrdiff_t>((ptrdiff_t)slice, hi - lo));
+    }
+  }
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; ++t)
+    th.emplace_back([&] {
+      for (size_t i; (i = next.fetch_add(1)) < slices.size();) (void)madvise(slices[i].first, slices[i].second, MADV_DONTNEED);
+    });
+  for (auto& t : th) t.join();
+}
+}  // namespace
+
+void* operator new(size_t n) {
+  void* p = malloc(n ? n : 1);
+  if (!p) throw std::bad_alloc();
+  if (n >= kBigAllocation) {
+    std::lock_guard<std::mutex> lk(g_big_mu);
+    if (!g_big) g_big = new (malloc(sizeof *g_big)) std::vector<std::pair<char*, size_t>>();
+    g_big->emplace_back((char*)p, n);
+  }
+  return p;
+}
+void* operator new[](size_t n) { return operator new(n); }
+void operator delete(void* p) noexcept {
+  if (!p) return;
+  if (g_big && malloc_usable_size(p) >= kBigAllocation) {  // (big blocks are few: a linear look is nothing beside their munmap)
+    std::lock_guard<std::mutex> lk(g_big_mu);
+    for (auto& b : *g_big)
+      if (b.first == (char*)p) {
+        b = g_big->back();
+        g_big->pop_back();
+        break;
+      }
+  }
+  free(p);
+}
+void operator delete[](void* p) noexcept { operator delete(p); }
+void operator delete(void* p, size_t) noexcept { operator delete(p); }
+void operator delete[](void* p, size_t) noexcept { operator delete(p); }
 
 int main(int argc, char** argv) {
   gmx::BatchedOptions opt;
@@ -42,13 +111,15 @@ int main(int argc, char** argv) {
       opt.device = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--groups") && a + 1 < argc)
       opt.groups = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--plain-exit"))
+      g_release_pages = false;  // (experiments: end as any process does)
     else if (!strcmp(argv[a], "--destroy"))
       opt.destroy_predictors = true;  // (experiments: the Predictors' destructors before the process ends)
     else
       break;
   }
   if (argc - a < 2) {
-    fprintf(stderr, "usage: %s [-d] [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--groups g] [--destroy] [--device d] <out dir> <input file>...\n", argv[0]);
+    fprintf(stderr, "usage: %s [-d] [-T chunk_bits] [-n bytes] [--no-pin] [--cpus n] [--groups g] [--destroy] [--plain-exit] [--device d] <out dir> <input file>...\n", argv[0]);
     return 2;
   }
   const std::string out_dir = argv[a++];
@@ -103,6 +174,12 @@ int main(int argc, char** argv) {
   fflush(stderr);
   // Every output file is closed and the line is out: the process ends HERE, without the destructors of 64 Predictors
   // (2 GB of address space each), of the pool (tens of gigabytes of device memory handed back piece by piece) and of the
-  // runtime -- a second and a half for 64 files, which the kernel does in a fraction when the process just ends.
+  // runtime -- a second and a half for 64 files, which the kernel does in a fraction when the process just ends; the
+  // Predictors' touched pages first, from all cores (above).
+  if (g_release_pages && !opt.destroy_predictors) {
+    int n = gmx::QuotaCpus();
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    ReleaseBigAllocations(n > 0 ? n : 1);
+  }
   _exit(failed ? 1 : 0);
 }

@@ -8,7 +8,7 @@ mkdir -p $W/f
 for i in $(seq 0 $((S-1))); do python3 scripts/corpus.py $W/f/$(printf %04d $i) $N $((i*1531)) > /dev/null; done
 dropin/_build/gmix_chain_many $W/c $W/f/* > /dev/null 2>&1
 C=$(for i in $(seq 0 $((S-1))); do echo $W/c/$i.gmix; done)
-for FLAG in "" "--destroy" "" "--destroy"; do
+for FLAG in ${FLAGS:-"--plain-exit" "" "--plain-exit" ""}; do
   T0=$(date +%s.%N)
   GMX_POOL_TRACE=1 dropin/_build/gmix_chain_many -d $FLAG $W/b $C > $W/j.json 2> $W/err
   T1=$(date +%s.%N)
