@@ -667,7 +667,6 @@ gmx_indirect_step_kernel(const GmxIndDev* __restrict__ dv, const GmxIndStepArgs 
   __shared__ uint8_t nsn[512], rmn[512];
   __shared__ uint32_t mwl[8];
   __shared__ __attribute__((aligned(16))) float pr[WITH_LSTM ? GMX_L_NO : 4];
-  __shared__ uint32_t lstm_ctx_lds[2];
   const int lane = threadIdx.x;
   const int s = blockIdx.x;
   // (the step's first launch: the stream's control words and records come in from pinned host memory with it -- a copy
@@ -682,51 +681,61 @@ gmx_indirect_step_kernel(const GmxIndDev* __restrict__ dv, const GmxIndStepArgs 
     rmn[i] = dv->rm_next[i];
   }
   if (lane < 8) mwl[lane] = 0;
-  __syncthreads();
-  if (WITH_LSTM && (what & 2u)) {
-    uint32_t c, act;
-    gmx_lstm_bitstep_body(ldv, la, s, what, pr, lane, /*mask_to_global=*/false, c, act);
-    if (lane == 0) {
-      lstm_ctx_lds[0] = c;
-      if (act) atomicOr(&mwl[la.slot >> 5], 1u << (la.slot & 31));  // (the host left the slot's bit clear)
-    }
-    __syncthreads();
-  }
+  // The LSTM's part begins: its byte distribution into LDS, and lstm_prediction_context -- a constant of the byte, so
+  // the model that reads it has it now and ALL of the Indirect models' loads below can be under way while lane 0 walks
+  // the distribution (the walk used to come first and everything else after it: two round trips more in the chain).
+  const bool with_lstm = WITH_LSTM && (what & 2u);
+  uint32_t lstm_ctx = 0;
+  if (with_lstm) lstm_ctx = gmx_lstm_bitstep_begin(ldv, la, s, pr, lane);
   const bool on = lane < K;
   uint8_t* const bank = a.banks + (uint64_t)s * dv->bank_bytes;
   uint32_t* const L = a.latch + ((uint64_t)s * 64 + lane) * 4;  // {index, entry, have, -}
   GmxIndModelDev d = dv->m[on ? lane : 0];
+  // Three dependent trips to memory instead of the seven of learn-then-predict written out in order: (1) everything
+  // that depends on nothing -- the latch, the step's context, the slots; (2) the learn's two logits AND the predict's
+  // table entry; (3) the predict's two logits.  What the learn writes and the predict would read again -- the entry,
+  // when the index repeats; a logit, when the state does -- is handed over in registers; the stores go out last.
+  uint16_t* const tab = (uint16_t*)(bank + d.tab_off);
+  float* const nsp = (float*)(bank + dv->pred_off) + (size_t)(on ? lane : 0) * 512;
+  float* const rmp = nsp + 256;
+  float* const slots = (float*)(bank + dv->slots_off);
+  uint32_t idx_old = 0, e_old = 0, have = 0, ctx = 0, bcu = 0;
+  float va = 0.f, vb = 0.f;
+  const bool do_pred = (what & 2u) != 0;
+  const int bit = a.bits[s] ? 1 : 0;
   if (on) {
-    // Three dependent trips to memory instead of the seven of learn-then-predict written out in order: (1) everything
-    // that depends on nothing -- the latch, the step's context, the slots; (2) the learn's two logits AND the predict's
-    // table entry; (3) the predict's two logits.  What the learn writes and the predict would read again -- the entry,
-    // when the index repeats; a logit, when the state does -- is handed over in registers; the stores go out last.
-    uint16_t* const tab = (uint16_t*)(bank + d.tab_off);
-    float* const nsp = (float*)(bank + dv->pred_off) + (size_t)lane * 512;
-    float* const rmp = nsp + 256;
-    float* const slots = (float*)(bank + dv->slots_off);
-    const uint32_t idx_old = L[0], e_old = L[1];
-    uint32_t have = L[2];
-    const bool do_learn = (what & 1u) && have;
-    const bool do_pred = (what & 2u) != 0;
-    const int bit = a.bits[s] ? 1 : 0;
-    uint32_t ctx = do_pred ? a.ctx[(uint64_t)s * K + lane] : 0u;
-    if (WITH_LSTM && do_pred && lane == la.ind_ctx_col) ctx = lstm_ctx_lds[0];  // (this launch's own store, not yet re-read)
-    const uint32_t bcu = do_pred ? a.bc[s] : 0u;
-    float va = slots[2 * lane], vb = slots[2 * lane + 1];
-    // ---- trip 2
-    const uint32_t ns_o = e_old & 255u, rm_o = e_old >> 8;
-    const uint32_t sn_o = ns_o != 255u ? ns_o : 0u;  // the uninitialised state learns as state 0
-    float pa = 0.f, pb = 0.f;
-    if (do_learn) {
-      pa = nsp[sn_o];
-      pb = rmp[rm_o];
-    }
-    uint32_t idx = idx_old, e = e_old;
+    idx_old = L[0];
+    e_old = L[1];
+    have = L[2];
     if (do_pred) {
-      idx = ((ctx << 8) + bcu) % d.size;  // indirect.cpp:31-32, 32-bit wrap
-      e = tab[idx];
+      ctx = a.ctx[(uint64_t)s * K + lane];
+      bcu = a.bc[s];
     }
+    va = slots[2 * lane];
+    vb = slots[2 * lane + 1];
+  }
+  if (with_lstm && lane == la.ind_ctx_col) ctx = lstm_ctx;
+  const bool do_learn = on && (what & 1u) && have;
+  // ---- trip 2
+  const uint32_t ns_o = e_old & 255u, rm_o = e_old >> 8;
+  const uint32_t sn_o = ns_o != 255u ? ns_o : 0u;  // the uninitialised state learns as state 0
+  float pa = 0.f, pb = 0.f;
+  if (do_learn) {
+    pa = nsp[sn_o];
+    pb = rmp[rm_o];
+  }
+  uint32_t idx = idx_old, e = e_old;
+  if (on && do_pred) {
+    idx = ((ctx << 8) + bcu) % d.size;  // indirect.cpp:31-32, 32-bit wrap
+    e = tab[idx];
+  }
+  __syncthreads();  // (the tables and the distribution are in LDS)
+  if (with_lstm) {  // ... while those are on their way: lane 0's walk down the distribution
+    uint32_t act;
+    gmx_lstm_bitstep_walk(ldv, la, s, what, lstm_ctx, pr, lane, /*mask_to_global=*/false, act);
+    if (lane == 0 && act) atomicOr(&mwl[la.slot >> 5], 1u << (la.slot & 31));  // (the host left the slot's bit clear)
+  }
+  if (on) {
     float na = 0.f, nb = 0.f;
     uint32_t e_upd = 0;
     if (do_learn) {  // Indirect::Learn (indirect.cpp:48-69)

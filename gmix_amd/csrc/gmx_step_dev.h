@@ -52,18 +52,26 @@ __device__ __forceinline__ void gmx_step_upload(const GmxStepUpload& u, int s, i
 }
 
 // LstmModel::Predict's walk down the byte distribution for ONE bit of stream s (lstm-model.cpp:34-48; see
-// gmx_lstm_bitstep_kernel).  Every thread of the block calls it (`pr`: 256 floats of LDS); the result is lane 0's.
-// ctx_out = lstm_prediction_context; mask_bit_out = whether SetPrediction marked the slot active.  mask_to_global:
-// set / clear the slot's bit in the mixers' mask record here (else the caller does).
-__device__ __forceinline__ void gmx_lstm_bitstep_body(const GmxLstmDev* __restrict__ dvp, const GmxLstmBitArgs& a, int s,
-                                                      uint32_t what, float* pr, int lane, bool mask_to_global,
-                                                      uint32_t& ctx_out, uint32_t& mask_bit_out) {
+// gmx_lstm_bitstep_kernel), in two parts so that a caller can put its own loads in between.  Every thread of the (one-wave)
+// block calls both (`pr`: 256 floats of LDS).  gmx_lstm_bitstep_begin copies the byte distribution into LDS and returns
+// lstm_prediction_context (a constant of the byte: Lstm::Predict stored it when the byte opened); gmx_lstm_bitstep_walk
+// is lane 0's: the range, the two ordered sums, the prediction into the mixers' record.  mask_bit_out = whether
+// SetPrediction marked the slot active.  mask_to_global: set / clear the slot's bit in the mixers' mask record here (else
+// the caller does).
+__device__ __forceinline__ uint32_t gmx_lstm_bitstep_begin(const GmxLstmDev* __restrict__ dvp, const GmxLstmBitArgs& a, int s,
+                                                           float* pr, int lane) {
+  float* const B = a.banks + (uint64_t)s * dvp->bank_floats;
+  const uint32_t* const scal = (const uint32_t*)(B + dvp->scal);
+  const float4 q = ((const float4*)(B + dvp->probs))[lane];
+  const uint32_t c = scal[4];
+  ((float4*)pr)[lane] = q;
+  return c;
+}
+__device__ __forceinline__ void gmx_lstm_bitstep_walk(const GmxLstmDev* __restrict__ dvp, const GmxLstmBitArgs& a, int s,
+                                                      uint32_t what, uint32_t c, const float* pr, int lane,
+                                                      bool mask_to_global, uint32_t& mask_bit_out) {
   float* const B = a.banks + (uint64_t)s * dvp->bank_floats;
   uint32_t* const scal = (uint32_t*)(B + dvp->scal);
-  const float4 q = ((const float4*)(B + dvp->probs))[lane];
-  ((float4*)pr)[lane] = q;
-  __syncthreads();
-  ctx_out = 0;
   mask_bit_out = 0;
   if (lane != 0) return;
   int top, bot;
@@ -118,11 +126,17 @@ __device__ __forceinline__ void gmx_lstm_bitstep_body(const GmxLstmDev* __restri
     const uint32_t m = 1u << (a.slot & 31);
     *w = active ? (*w | m) : (*w & ~m);
   }
-  const uint32_t c = scal[4];
   if (a.mixer_ctx_col >= 0) a.mx_ctx[(uint64_t)s * a.mx_m + a.mixer_ctx_col] = c;
   if (a.ind_ctx && a.ind_ctx_col >= 0) a.ind_ctx[(uint64_t)s * a.ind_k + a.ind_ctx_col] = c;
-  ctx_out = c;
   mask_bit_out = active ? 1u : 0u;
+}
+// Both, one after the other (gmx_lstm_bitstep_kernel).
+__device__ __forceinline__ void gmx_lstm_bitstep_body(const GmxLstmDev* __restrict__ dvp, const GmxLstmBitArgs& a, int s,
+                                                      uint32_t what, float* pr, int lane, bool mask_to_global,
+                                                      uint32_t& ctx_out, uint32_t& mask_bit_out) {
+  ctx_out = gmx_lstm_bitstep_begin(dvp, a, s, pr, lane);
+  __syncthreads();
+  gmx_lstm_bitstep_walk(dvp, a, s, what, ctx_out, pr, lane, mask_to_global, mask_bit_out);
 }
 
 #endif  // GMX_STEP_DEV_H_
