@@ -672,8 +672,8 @@ gmx_indirect_step_kernel(const GmxIndDev* __restrict__ dv, const GmxIndStepArgs 
   // (the step's first launch: the stream's control words and records come in from pinned host memory with it -- a copy
   // kernel in front cost the step 6 us; a.what and everything else below point into the device copy it fills)
   if (a.up.n > 0) gmx_step_upload(a.up, s, lane);
+  // (what the stream asks is tested only where it is first needed: everything up to there is requested together with it)
   const uint32_t what = a.what[s];
-  if (!(what & 3u)) return;
   const int K = dv->k;
   if (lane < 32) s_tab[lane] = gmx_exp2f_tab[lane];
   for (int i = lane; i < 512; i += 64) {
@@ -684,9 +684,8 @@ gmx_indirect_step_kernel(const GmxIndDev* __restrict__ dv, const GmxIndStepArgs 
   // The LSTM's part begins: its byte distribution into LDS, and lstm_prediction_context -- a constant of the byte, so
   // the model that reads it has it now and ALL of the Indirect models' loads below can be under way while lane 0 walks
   // the distribution (the walk used to come first and everything else after it: two round trips more in the chain).
-  const bool with_lstm = WITH_LSTM && (what & 2u);
   uint32_t lstm_ctx = 0;
-  if (with_lstm) lstm_ctx = gmx_lstm_bitstep_begin(ldv, la, s, pr, lane);
+  if (WITH_LSTM) lstm_ctx = gmx_lstm_bitstep_begin(ldv, la, s, pr, lane);
   const bool on = lane < K;
   uint8_t* const bank = a.banks + (uint64_t)s * dv->bank_bytes;
   uint32_t* const L = a.latch + ((uint64_t)s * 64 + lane) * 4;  // {index, entry, have, -}
@@ -699,21 +698,21 @@ gmx_indirect_step_kernel(const GmxIndDev* __restrict__ dv, const GmxIndStepArgs 
   float* const nsp = (float*)(bank + dv->pred_off) + (size_t)(on ? lane : 0) * 512;
   float* const rmp = nsp + 256;
   float* const slots = (float*)(bank + dv->slots_off);
-  uint32_t idx_old = 0, e_old = 0, have = 0, ctx = 0, bcu = 0;
+  uint32_t idx_old = 0, e_old = 0, have = 0, ctx = 0;
   float va = 0.f, vb = 0.f;
-  const bool do_pred = (what & 2u) != 0;
   const int bit = a.bits[s] ? 1 : 0;
+  const uint32_t bcu = a.bc[s];
   if (on) {
     idx_old = L[0];
     e_old = L[1];
     have = L[2];
-    if (do_pred) {
-      ctx = a.ctx[(uint64_t)s * K + lane];
-      bcu = a.bc[s];
-    }
+    ctx = a.ctx[(uint64_t)s * K + lane];
     va = slots[2 * lane];
     vb = slots[2 * lane + 1];
   }
+  if (!(what & 3u)) return;  // the stream sits the step out
+  const bool do_pred = (what & 2u) != 0;
+  const bool with_lstm = WITH_LSTM && do_pred;
   if (with_lstm && lane == la.ind_ctx_col) ctx = lstm_ctx;
   const bool do_learn = on && (what & 1u) && have;
   // ---- trip 2
