@@ -59,8 +59,8 @@ def same_outputs(stock_dir, batched_dir):
     return a
 
 
-def run_many(name, files, out_dir, chunk_bits, timeout=1100, extra=()):
+def run_many(name, files, out_dir, chunk_bits, timeout=1100, extra=(), env=None):
     r = subprocess.run([exe(name), "-T", str(chunk_bits), *extra, str(out_dir)] + [str(f) for f in files],
-                       capture_output=True, text=True, timeout=timeout)
+                       capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **env) if env else None)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     return json.loads(r.stdout.strip().splitlines()[-1])
