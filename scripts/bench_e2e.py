@@ -186,6 +186,12 @@ def measure_decode(streams=64, n_bytes=4000, variant="chain", verify=True, cpu=T
         if r.returncode != 0:
             raise RuntimeError(f"{EXE[variant]} failed: {r.stderr[-500:]}")
         coded = [os.path.join(tmp, "c", f"{k}.gmix") for k in range(S)]
+        # The compression that made the files has just given back S x 1 GB of device memory, and the driver clears it in
+        # the background before it hands any of it out again -- 7 s for 256 streams' 247 GB, during which a new process's
+        # allocations wait (scripts/exp_vram_reuse.sh: banks up in 0.19 s after a pause, 2.3-4.0 s without).  That is the
+        # preparation's wake, not the decompressor's cost: let it pass before the clock starts.
+        settle = 0.03 * S
+        time.sleep(settle)
         t0 = time.perf_counter()
         r = subprocess.run([exe, "-d"] + dev + [os.path.join(tmp, "back")] + coded, capture_output=True, text=True,
                            timeout=1500)
@@ -204,7 +210,7 @@ def measure_decode(streams=64, n_bytes=4000, variant="chain", verify=True, cpu=T
                           "streams": S, "bytes_per_file": n_bytes, "variant": variant, "worker_threads": st["pinned_cpus"],
                           "host_cpu": host_cpu(), "cpu_quota_cores": quota},
                "seconds": process_seconds, "coding_loops_seconds": st["wall_seconds"], "setup_seconds": st["build_seconds"],
-               "in_process_seconds": st["total_seconds"], "steps": st["launches"],
+               "in_process_seconds": st["total_seconds"], "steps": st["launches"], "settled_seconds_before_the_clock": settle,
                "us_per_step": st["wall_seconds"] * 1e6 / max(1, st["launches"])}
         if verify:
             out["identical_to_stock"] = all(open(os.path.join(tmp, "back", f"{k}.out"), "rb").read() == open(files[k], "rb").read()
